@@ -1,0 +1,179 @@
+/*
+ * vitssl_hip.h -- C ABI of libvitssl_hip.so, the MI355X (gfx950) compute library
+ * behind the vit_core hot path of kristi700/ViT-SSL.
+ *
+ * The reference has no FFI layer: its "operator interface" for this path is the
+ * set of torch ops that vit_core lowers to.  Each
+ * entry point below names the reference lines it replaces (paths relative to the
+ * reference repo root).  The Python host mirror (vit-ssl_amd/) binds these with
+ * ctypes; see INTEGRATION.md for the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - every entry returns 0 on success, <0 on error; vitssl_last_error() gives text
+ *   - no allocation, no ownership transfer: all pointers are device pointers owned
+ *     by the caller (torch-allocated); shapes are passed explicitly
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*); no entry
+ *     synchronises the device
+ *   - bf16 tensors are passed as void* (raw uint16 storage), fp32 as float*
+ *   - all matrices are dense row-major; "ld" is always the logical column count
+ *   - re-entrant: no global mutable state (safe from autograd's backward thread)
+ */
+#ifndef VITSSL_HIP_H
+#define VITSSL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VITSSL_OK 0
+#define VITSSL_ERR_ARG (-1)     /* bad shape / unsupported configuration */
+#define VITSSL_ERR_LAUNCH (-2)  /* HIP launch error */
+
+const char* vitssl_last_error(void);
+int vitssl_version(void);
+
+/* ---- dropout stream -------------------------------------------------------
+ * Counter-based: keep(e) = bits16(seed, site, e) >= round(p * 65536) for element
+ * index e = row * ld + col of the tensor the dropout acts on.  The same triple
+ * regenerates the mask in backward.  Replaces nn.Dropout at
+ * vit_core/encoder_block.py:29-30,45,51 and vit_core/feed_forward.py:16,27. */
+typedef struct {
+  float p;        /* drop probability; 0 disables */
+  uint32_t site;  /* per (block, site) stream id */
+  uint64_t seed;  /* per-step seed */
+} vitssl_dropout_t;
+
+/* Materialise the 0/1 keep mask (uint8 [rows*cols]); test/debug helper. */
+int vitssl_dropout_mask(uint8_t* keep, int64_t rows, int64_t cols, vitssl_dropout_t d, void* stream);
+
+/* ---- LayerNorm (nn.LayerNorm eps=1e-5 affine; vit_core/encoder_block.py:26-27,41,49;
+ *      vit_core/mlp_head.py:9,13) ------------------------------------------- */
+/* y_bf16[rows,cols] = LN(x) ; saves mean/rstd [rows] (fp32 statistics). */
+int vitssl_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16,
+                         float* mean, float* rstd, int64_t rows, int cols, float eps, void* stream);
+
+/* g_out = g_res + LN'(dy); optionally also emits the dropout-masked bf16 copy that
+ * the next (reverse-order) GEMM consumes, and its column sum (bias gradient).
+ *   dy_bf16      [rows,cols] gradient wrt the LN output (bf16)
+ *   g_res        [rows,cols] fp32 residual-branch gradient, may be NULL
+ *   g_out        [rows,cols] fp32, may alias g_res
+ *   gm_bf16      [rows,cols] bf16 = keepmask(drop) * g_out / (1-p), may be NULL
+ *   dgamma/dbeta [cols] fp32, ATOMICALLY ACCUMULATED (caller zeroes)
+ *   gm_colsum    [cols] fp32 accumulated column sums of gm_bf16, may be NULL */
+int vitssl_layernorm_bwd(const void* dy_bf16, const float* x, const float* mean, const float* rstd,
+                         const float* gamma, const float* g_res, float* g_out, void* gm_bf16,
+                         float* dgamma, float* dbeta, float* gm_colsum, vitssl_dropout_t drop,
+                         int64_t rows, int cols, void* stream);
+
+/* Standalone "mask + cast + column-sum" of an fp32 gradient (top of the backward chain). */
+int vitssl_grad_mask_cast(const float* g, void* gm_bf16, float* gm_colsum, vitssl_dropout_t drop,
+                          int64_t rows, int cols, void* stream);
+
+/* ---- bf16 MFMA GEMM, C[M,N] = A[M,K] . B[N,K]^T, fp32 accumulate ----------------
+ * (nn.Linear at vit_core/attention.py:54-58,82-84,105; feed_forward.py:14-15,26-28;
+ *  ssl/simmim/model.py:28-30,35-37,45,57; Conv2d k=s=P at patch_embedding.py:22,79-84;
+ *  mlp_head.py:10,14; ssl/dino/head.py:10-17,20,22 -- and their autograd dgrads,
+ *  which are the same contraction against the transposed weight copy). */
+enum {
+  VITSSL_EPI_BF16 = 0,         /* out0(bf16) = acc + bias                                         */
+  VITSSL_EPI_F32 = 1,          /* out0(f32)  = acc + bias                                         */
+  VITSSL_EPI_GELU = 2,         /* out0(bf16) = u = acc + bias ; out1(bf16) = drop(gelu_erf(u))    */
+  VITSSL_EPI_RESID = 3,        /* out0(f32)  = aux(f32 [M,N]) + drop(acc + bias)                  */
+  VITSSL_EPI_DGELU = 4,        /* out0(bf16) = acc * dropmask * gelu'(aux(bf16 u [M,N]))          */
+  VITSSL_EPI_EMBED = 5         /* patch-embedding epilogue, see vitssl_embed_t                    */
+};
+
+/* Extra arguments of VITSSL_EPI_EMBED: token = mask ? mask_token : (acc + bias);
+ * token += pos[row_in_img + tok_offset]; stored (fp32) at
+ * out0[(img * out_tokens + tok_offset + row_in_img), :].
+ * (vit_core/ssl/simmim/model.py:45-49; patch_embedding.py:58-63,92-95,125-127) */
+typedef struct {
+  const uint8_t* mask;      /* [M] 1 = masked token, NULL = none */
+  const float* mask_token;  /* [N] */
+  const float* pos;         /* [out_tokens, N] (already interpolated if needed) */
+  int tokens;               /* patches per image (rows of A per image) */
+  int out_tokens;           /* tokens per image in the output (tokens + tok_offset) */
+  int tok_offset;           /* 1 when a CLS slot precedes the patches, else 0 */
+} vitssl_embed_t;
+
+typedef struct {
+  const void* A;            /* bf16 [M,K] */
+  const void* B;            /* bf16 [N,K] */
+  int64_t M;
+  int N, K;                 /* K % 64 == 0, N % 4 == 0 */
+  int epilogue;
+  const float* bias;        /* [N] or NULL */
+  const void* aux;          /* epilogue-specific input or NULL */
+  void* out0;
+  void* out1;
+  float* colsum;            /* [N] accumulated column sums of out0 (bias grad), or NULL */
+  vitssl_dropout_t drop;
+  vitssl_embed_t embed;
+} vitssl_gemm_t;
+
+int vitssl_gemm_bf16_nt(const vitssl_gemm_t* g, void* stream);
+
+/* Weight gradient: C[N1,N2] (fp32) += A[M,N1]^T . B[M,N2]  (contraction over rows).
+ * Split over M across workgroups, combined with fp32 atomics: caller zeroes C.
+ * N1 % 8 == 0, N2 % 8 == 0. */
+int vitssl_gemm_bf16_tn(const void* A, const void* B, float* C, int64_t M, int N1, int N2, void* stream);
+
+/* ---- fused multi-head self-attention (vit_core/attention.py:20-23,86-103) ----------
+ * qkv  bf16 [B, N, 3, H, dh]  (the fused projection output: q | k | v per token)
+ * out  bf16 [B, N, H*dh]      (heads merged, ready for final_linear)
+ * lse  f32  [B, H, N]         (log-sum-exp of the scaled scores, saved for backward)
+ * probs f32 [B, H, N, N] or NULL (return_attn=True path)
+ * dh in {32, 64, 128}; scale = 1/sqrt(dh). */
+int vitssl_attn_fwd(const void* qkv, void* out, float* lse, float* probs, int B, int N, int H, int dh,
+                    void* stream);
+/* delta_ws: f32 [B,H,N] scratch (rowsum(dO*O)); dqkv bf16 [B,N,3,H,dh] fully overwritten. */
+int vitssl_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                    float* delta_ws, int B, int N, int H, int dh, void* stream);
+
+/* ---- patch handling (nn.Unfold + permute, ssl/simmim/model.py:27,43; masking.py:35) */
+/* img f32 [B,C,H,W] -> patches bf16 [B*gh*gw, C*P*P], feature order (c,kh,kw). */
+int vitssl_patchify_bf16(const float* img, void* patches, int B, int C, int H, int W, int P, void* stream);
+/* targets f32 [n_idx, C*P*P] = patches[idx] gathered straight from the image (exact fp32). */
+int vitssl_gather_patches_f32(const float* img, const int32_t* idx, float* out, int n_idx, int C, int H,
+                              int W, int P, void* stream);
+/* out bf16 [n_idx, cols] = x f32 [rows, cols][idx]   (x[bool_mask], ssl/simmim/model.py:56) */
+int vitssl_gather_rows_bf16(const float* x, const int32_t* idx, void* out, int n_idx, int cols, void* stream);
+/* g f32 [rows, cols] = 0 except g[idx[i]] = src_bf16[i]; inv[row] = i or -1 */
+int vitssl_scatter_rows_f32(const void* src_bf16, const int32_t* inv, float* g, int64_t rows, int cols,
+                            void* stream);
+/* CLS-row helpers for ViT / DINO (x[:,0], vit_core/vit.py:39): f32 [B, T, D] row 0 of each image */
+int vitssl_gather_cls_f32(const float* x, float* out, int B, int T, int D, void* stream);
+int vitssl_scatter_cls_f32(const float* gcls, float* g, int B, int T, int D, void* stream);
+
+/* Patch-embedding backward glue: from dtok f32 [B*T_out, D] produce the bf16 operand
+ * of the projection wgrad (masked rows zeroed, CLS rows dropped) and accumulate
+ * d(pos) [T_out, D], d(mask_token) [D], d(bias) [D], d(cls_token) [D]. */
+int vitssl_embed_bwd(const float* dtok, const uint8_t* mask, void* dproj_bf16, float* dpos, float* dmask_token,
+                     float* dbias, float* dcls, int B, int tokens, int tok_offset, int D, void* stream);
+
+/* ---- losses ------------------------------------------------------------------- */
+/* nn.L1Loss(mean) (configs/simmim/training.yaml:2-5): loss_sum += sum|p-t| (caller zeroes,
+ * divides by n); dpred_bf16 = sign(p-t) * gscale (gscale = upstream_grad / n) or NULL. */
+int vitssl_l1_loss(const float* pred, const float* target, float* loss_sum, void* dpred_bf16, float gscale,
+                   int64_t n, void* stream);
+/* nn.CrossEntropyLoss(mean) on f32 logits [B,C]; dlogits_bf16 = (softmax - onehot) * gscale */
+int vitssl_cross_entropy(const float* logits, const int64_t* labels, float* loss_sum, void* dlogits_bf16,
+                         float gscale, int B, int C, void* stream);
+
+/* ---- parameter plumbing ----------------------------------------------------------- */
+int vitssl_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* dst_t bf16 [C,R] = transpose(src f32 [R,C]) ; dst bf16 [R,C] = src (either may be NULL) */
+int vitssl_cast_transpose_bf16(const float* src, void* dst, void* dst_t, int R, int C, void* stream);
+/* torch.optim.AdamW step over a flat fp32 buffer (utils/train_utils.py:25-29). step is 1-based;
+ * g is multiplied by gscale first (1/world_size for DP averaging). */
+int vitssl_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                 float eps, float wd, int step, float gscale, void* stream);
+/* teacher = m*teacher + (1-m)*student over flat buffers (ssl/dino/model.py:126-139) */
+int vitssl_ema(float* teacher, const float* student, int64_t n, float m, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITSSL_HIP_H */

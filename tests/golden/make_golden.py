@@ -97,10 +97,10 @@ def masking_case():
 
 def ops_case():
     torch.manual_seed(11)
-    q, k, v = (torch.randn(2, 3, 20, 8) for _ in range(3))
+    q, k, v = (torch.randn(2, 3, 20, 64) for _ in range(3))
     o, p = ScaledDotProductAttention(q, k, v, return_attn=True)
-    blk = EncoderBlock(d_model=32, num_heads=4, mlp_dim=64, dropout=0.0)
-    x = torch.randn(3, 10, 32, requires_grad=True)
+    blk = EncoderBlock(d_model=128, num_heads=2, mlp_dim=192, dropout=0.0)
+    x = torch.randn(3, 10, 128, requires_grad=True)
     y, probs = blk(x, return_attn=True)
     y.square().sum().backward()
     arrs = dict(q=npy(q), k=npy(k), v=npy(v), o=npy(o), p=npy(p), blk_x=npy(x), blk_y=npy(y),
@@ -112,7 +112,7 @@ def ops_case():
 
 def vit_case():
     torch.manual_seed(21)
-    B, img, patch, D, H, F, blocks, C = 4, 32, 8, 64, 4, 128, 2, 10
+    B, img, patch, D, H, F, blocks, C = 4, 32, 8, 128, 2, 192, 2, 10
     model = ViT(num_classes=C, num_blocks=blocks, input_shape=(3, img, img), embed_dim=D, patch_size=patch,
                 num_heads=H, mlp_dim=F, dropout=0.0)
     xu8 = img_u8((B, 3, img, img), 22)
@@ -127,7 +127,7 @@ def vit_case():
 
 def dino_case():
     torch.manual_seed(31)
-    B, gi, li, patch, D, H, F, blocks, K = 2, 32, 16, 8, 64, 4, 128, 1, 256
+    B, gi, li, patch, D, H, F, blocks, K = 2, 32, 16, 8, 64, 1, 128, 1, 256
     G, L = 2, 2
     model = DINOViT(num_blocks=blocks, input_shape=(3, gi, gi), embed_dim=D, patch_size=patch, num_heads=H,
                     mlp_dim=F, dropout=0.0, output_dim=K, center_momentum=0.9)
@@ -204,8 +204,8 @@ if __name__ == "__main__":
     torch.set_num_threads(4)
     masking_case()
     ops_case()
-    simmim_case("simmim_tiny", seed=100, B=2, img=32, patch=8, D=64, H=4, F=128, blocks=2, ratio=0.6)
-    simmim_case("simmim_n196", seed=200, B=2, img=224, patch=16, D=64, H=2, F=128, blocks=1, ratio=0.6)
+    simmim_case("simmim_tiny", seed=100, B=3, img=32, patch=8, D=128, H=2, F=192, blocks=2, ratio=0.6)
+    simmim_case("simmim_n196", seed=200, B=2, img=224, patch=16, D=64, H=1, F=128, blocks=1, ratio=0.6)
     vit_case()
     dino_case()
     adamw_case()

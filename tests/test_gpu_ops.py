@@ -1,0 +1,424 @@
+"""Op-level parity of every HIP kernel against the CPU oracle / plain fp32 torch math
+on the same seeded inputs.  All calls go through the C ABI (vitssl_hip.ops).
+
+Tolerances: bf16 outputs are compared after the reference is rounded the same way:
+|got - ref| <= 2^-7 |ref| + atol (one bf16 ulp of slack for accumulation-order
+differences); fp32 outputs to 1e-5..1e-4 relative; integer/byte/gather work bit-exact."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from _util import load_golden, t, rel_l2, max_abs
+from oracle import vit_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from vitssl_hip import ops as _ops
+    return _ops
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def close_bf16(got, ref, atol=2e-3, what=""):
+    got = got.float().cpu()
+    ref = ref.float().cpu()
+    err = (got - ref).abs()
+    lim = ref.abs() * 2.0 ** -7 + atol
+    bad = err > lim
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} outside bf16 tolerance, max err {float(err.max())}"
+
+
+def gpu(x):
+    return x.to(DEV).contiguous()
+
+
+# ----------------------------------------------------------------------------- dropout stream
+def test_dropout_mask_statistics(ops):
+    rows, cols = 512, 768
+    d = ops.make_dropout(0.1, seed=1234, site=3)
+    k1 = ops.dropout_mask(rows, cols, d, DEV).cpu()
+    k2 = ops.dropout_mask(rows, cols, d, DEV).cpu()
+    assert torch.equal(k1, k2)                                   # same (seed, site) -> same mask
+    n = rows * cols
+    p_eff = round(0.1 * 65536) / 65536
+    keep = float(k1.float().mean())
+    assert abs(keep - (1 - p_eff)) < 5 * math.sqrt(p_eff * (1 - p_eff) / n)
+    k3 = ops.dropout_mask(rows, cols, ops.make_dropout(0.1, seed=1234, site=4), DEV).cpu()
+    k4 = ops.dropout_mask(rows, cols, ops.make_dropout(0.1, seed=1235, site=3), DEV).cpu()
+    for other in (k3, k4):                                        # independent streams
+        agree = float((other == k1).float().mean())
+        assert abs(agree - ((1 - p_eff) ** 2 + p_eff ** 2)) < 0.01
+    # no visible column / row structure
+    assert float(k1.float().mean(dim=0).std()) < 0.03 and float(k1.float().mean(dim=1).std()) < 0.03
+    assert bool(ops.dropout_mask(8, 64, ops.make_dropout(0.0), DEV).all())
+
+
+# ----------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("cols", [64, 192, 384, 768, 1024, 2048])
+def test_layernorm_fwd_bwd(ops, cols):
+    torch.manual_seed(cols)
+    rows = 301
+    x = torch.randn(rows, cols) * 2 + 0.5
+    gamma = torch.rand(cols) + 0.5
+    beta = torch.randn(cols) * 0.1
+    y = torch.empty(rows, cols, dtype=torch.bfloat16, device=DEV)
+    mean = torch.empty(rows, device=DEV)
+    rstd = torch.empty(rows, device=DEV)
+    ops.layernorm_fwd(gpu(x), gpu(gamma), gpu(beta), y, mean, rstd)
+    ref = O.layer_norm(x, gamma, beta)
+    close_bf16(y, bf(ref), what="ln fwd")
+    assert max_abs(mean, x.mean(-1)) < 1e-5
+    assert rel_l2(rstd, torch.rsqrt(x.var(-1, unbiased=False) + 1e-5)) < 1e-5
+
+    dy = bf(torch.randn(rows, cols))
+    g_res = torch.randn(rows, cols)
+    xr = x.clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    br = beta.clone().requires_grad_(True)
+    (O.layer_norm(xr, gr, br) * dy.float()).sum().backward()
+    for p, site in ((0.0, 0), (0.25, 7)):
+        g_out = torch.empty(rows, cols, device=DEV)
+        gm = torch.empty(rows, cols, dtype=torch.bfloat16, device=DEV)
+        dgamma = torch.zeros(cols, device=DEV)
+        dbeta = torch.zeros(cols, device=DEV)
+        cs = torch.zeros(cols, device=DEV)
+        drop = ops.make_dropout(p, seed=99, site=site)
+        ops.layernorm_bwd(gpu(dy), gpu(x), mean, rstd, gpu(gamma), gpu(g_res), g_out, gm, dgamma, dbeta, cs, drop)
+        ref_g = xr.grad + g_res
+        assert rel_l2(g_out, ref_g) < 1e-5
+        assert rel_l2(dgamma, gr.grad) < 1e-4 and rel_l2(dbeta, br.grad) < 1e-4
+        keep = ops.dropout_mask(rows, cols, drop, DEV).cpu().float()
+        scale = 1.0 if p == 0 else 65536.0 / (65536 - round(p * 65536))
+        ref_gm = ref_g * keep * scale
+        close_bf16(gm, bf(ref_gm), what="ln bwd gm")
+        assert rel_l2(cs, ref_gm.sum(0)) < 1e-3
+    # standalone mask+cast
+    gm2 = torch.empty(rows, cols, dtype=torch.bfloat16, device=DEV)
+    cs2 = torch.zeros(cols, device=DEV)
+    ops.grad_mask_cast(gpu(g_res), gm2, cs2)
+    assert torch.equal(gm2.cpu(), bf(g_res))
+    assert rel_l2(cs2, g_res.sum(0)) < 1e-4
+
+
+# ----------------------------------------------------------------------------- GEMM NT
+def _ref_acc(A, B):
+    return A.float().cpu().double() @ B.float().cpu().double().t()
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 192, 64), (544, 768, 192), (1000, 260, 128), (257, 2304, 768), (37, 12, 64)])
+def test_gemm_nt_epilogues(ops, M, N, K):
+    from vitssl_hip import _lib as L
+    torch.manual_seed(M + N + K)
+    A = bf(torch.randn(M, K) * 0.5)
+    B = bf(torch.randn(N, K) * 0.5)
+    bias = torch.randn(N)
+    acc = _ref_acc(A, B).float()
+    Ad, Bd, biasd = gpu(A), gpu(B), gpu(bias)
+
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    cs = torch.zeros(N, device=DEV)
+    ops.gemm_nt(Ad, Bd, out, L.EPI_BF16, bias=biasd, colsum=cs)
+    close_bf16(out, bf(acc + bias), atol=5e-3, what="EPI_BF16")
+    assert rel_l2(cs, (acc + bias).sum(0)) < 1e-3
+    ops.gemm_nt(Ad, Bd, out, L.EPI_BF16)                       # no bias
+    close_bf16(out, bf(acc), atol=5e-3, what="EPI_BF16 nobias")
+
+    out32 = torch.empty(M, N, device=DEV)
+    ops.gemm_nt(Ad, Bd, out32, L.EPI_F32, bias=biasd)
+    assert rel_l2(out32, acc + bias) < 1e-5
+
+    # GELU (+ dropout)
+    for p in (0.0, 0.3):
+        drop = ops.make_dropout(p, seed=5, site=11)
+        u = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        a = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        ops.gemm_nt(Ad, Bd, u, L.EPI_GELU, bias=biasd, out1=a, drop=drop)
+        close_bf16(u, bf(acc + bias), atol=5e-3, what="EPI_GELU u")
+        keep = ops.dropout_mask(M, N, drop, DEV).cpu().float()
+        scale = 1.0 if p == 0 else 65536.0 / (65536 - round(p * 65536))
+        ref_a = O.gelu_erf(u.float().cpu()) * keep * scale     # gelu of the STORED bf16 u
+        close_bf16(a, bf(ref_a), atol=2e-3, what="EPI_GELU a")
+        # DGELU: out = acc * keep*scale * gelu'(u)
+        du = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        cs.zero_()
+        ops.gemm_nt(Ad, Bd, du, L.EPI_DGELU, aux=u, colsum=cs, drop=drop)
+        uu = u.float().cpu().double().requires_grad_(True)
+        (0.5 * uu * (1 + torch.erf(uu / math.sqrt(2)))).sum().backward()
+        ref_du = (acc.double() * keep * scale * uu.grad).float()
+        close_bf16(du, bf(ref_du), atol=5e-3, what="EPI_DGELU")
+        assert rel_l2(cs, ref_du.sum(0)) < 2e-3
+
+        res = torch.randn(M, N)
+        outr = torch.empty(M, N, device=DEV)
+        ops.gemm_nt(Ad, Bd, outr, L.EPI_RESID, bias=biasd, aux=gpu(res), drop=drop)
+        assert rel_l2(outr, res + (acc + bias) * keep * scale) < 1e-5
+
+
+def test_gemm_nt_embed_epilogue(ops):
+    from vitssl_hip import _lib as L
+    torch.manual_seed(0)
+    Bimg, tokens, N, K = 3, 16, 128, 192
+    M = Bimg * tokens
+    A = bf(torch.randn(M, K) * 0.3)
+    W = bf(torch.randn(N, K) * 0.3)
+    bias = torch.randn(N)
+    acc = _ref_acc(A, W).float() + bias
+    for tok_offset, use_mask in ((0, True), (1, False), (0, False)):
+        out_tokens = tokens + tok_offset
+        pos = torch.rand(out_tokens, N)
+        mask = (torch.rand(M) < 0.5).to(torch.uint8) if use_mask else None
+        mtok = torch.randn(N)
+        out = torch.full((Bimg * out_tokens, N), -7.0, device=DEV)
+        ops.gemm_nt(gpu(A), gpu(W), out, L.EPI_EMBED, bias=gpu(bias),
+                    embed=(None if mask is None else gpu(mask), gpu(mtok), gpu(pos), tokens, out_tokens, tok_offset))
+        tok = acc.view(Bimg, tokens, N).clone()
+        if mask is not None:
+            tok = torch.where(mask.view(Bimg, tokens, 1).bool(), mtok, tok)
+        tok = tok + pos[tok_offset:]
+        got = out.cpu().view(Bimg, out_tokens, N)
+        assert rel_l2(got[:, tok_offset:], tok) < 1e-5
+        if tok_offset:
+            assert bool((got[:, 0] == -7.0).all())       # CLS slot untouched by the kernel
+
+
+def test_gemm_nt_rejects_bad_shapes(ops):
+    from vitssl_hip import _lib as L
+    A = torch.zeros(8, 96, dtype=torch.bfloat16, device=DEV)
+    B = torch.zeros(16, 96, dtype=torch.bfloat16, device=DEV)
+    out = torch.zeros(8, 16, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(L.VitsslError):
+        ops.gemm_nt(A, B, out, L.EPI_BF16)                       # K % 64 != 0
+    with pytest.raises(L.VitsslError):
+        ops.gemm_nt(A.cpu(), B, out, L.EPI_BF16)                 # no CPU fallback
+
+
+# ----------------------------------------------------------------------------- GEMM TN (wgrad)
+@pytest.mark.parametrize("M,N1,N2", [(100, 64, 192), (544, 768, 264), (5000, 192, 768), (50176 // 8, 768, 768), (63, 8, 8)])
+def test_gemm_tn(ops, M, N1, N2):
+    torch.manual_seed(M)
+    A = bf(torch.randn(M, N1) * 0.5)
+    B = bf(torch.randn(M, N2) * 0.5)
+    Cacc = torch.zeros(N1, N2, device=DEV)
+    ops.gemm_tn(gpu(A), gpu(B), Cacc)
+    ref = (A.float().double().t() @ B.float().double()).float()
+    assert rel_l2(Cacc, ref) < 1e-5
+    ops.gemm_tn(gpu(A), gpu(B), Cacc)                            # accumulates
+    assert rel_l2(Cacc, 2 * ref) < 1e-5
+
+
+# ----------------------------------------------------------------------------- attention
+def _attn_ref(qkv, Bn, N, H, dh, emu="bf16"):
+    x = qkv.float().view(Bn, N, 3, H, dh)
+    q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))      # [B,H,N,dh]
+    o, p = O.sdpa(q, k, v, emu)
+    s = (q @ k.transpose(-2, -1)) / math.sqrt(dh)
+    lse = torch.logsumexp(s, dim=-1)
+    return o.transpose(1, 2).reshape(Bn * N, H * dh), p, lse
+
+
+@pytest.mark.parametrize("N", [5, 17, 37, 64, 145, 196, 197, 256])
+def test_attention_fwd_bwd(ops, N):
+    torch.manual_seed(N)
+    Bn, H, dh = 2, 3, 64
+    qkv = bf(torch.randn(Bn * N, 3 * H * dh))
+    out = torch.empty(Bn * N, H * dh, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(Bn, H, N, device=DEV)
+    probs = torch.empty(Bn, H, N, N, device=DEV)
+    ops.attn_fwd(gpu(qkv), out, lse, Bn, N, H, dh, probs=probs)
+    ro, rp, rl = _attn_ref(qkv, Bn, N, H, dh)
+    assert rel_l2(probs, rp) < 1e-3 and max_abs(probs, rp) < 2e-4
+    assert max_abs(lse, rl) < 1e-4
+    close_bf16(out, bf(ro), atol=4e-3, what="attn out")
+    out2 = torch.empty_like(out)
+    ops.attn_fwd(gpu(qkv), out2, lse, Bn, N, H, dh)               # probs=None path
+    assert torch.equal(out, out2)
+
+    dout = bf(torch.randn(Bn * N, H * dh))
+    leaf = qkv.float().clone().requires_grad_(True)
+    ro2, _, _ = _attn_ref(leaf, Bn, N, H, dh, emu=None)
+    (ro2 * dout.float()).sum().backward()
+    dqkv = torch.full((Bn * N, 3 * H * dh), float("nan"), dtype=torch.bfloat16, device=DEV)
+    delta = torch.empty(Bn, H, N, device=DEV)
+    ops.attn_bwd(gpu(qkv), out, gpu(dout), lse, dqkv, delta, Bn, N, H, dh)
+    got = dqkv.float().cpu().view(Bn, N, 3, H, dh)
+    ref = leaf.grad.view(Bn, N, 3, H, dh)
+    assert not torch.isnan(got).any()
+    for i, name in enumerate("qkv"):
+        assert rel_l2(got[:, :, i], ref[:, :, i]) < 2e-2, name
+
+
+def test_attention_golden(ops):
+    """reference ScaledDotProductAttention vectors (tests/golden/ops.npz), N=20, dh=64."""
+    g = load_golden("ops")
+    q, k, v = t(g["q"]), t(g["k"]), t(g["v"])                     # [2,3,20,64]
+    Bn, H, N, dh = q.shape
+    qkv = torch.stack([q, k, v], dim=2).permute(0, 3, 2, 1, 4).reshape(Bn * N, 3 * H * dh)
+    out = torch.empty(Bn * N, H * dh, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(Bn, H, N, device=DEV)
+    probs = torch.empty(Bn, H, N, N, device=DEV)
+    ops.attn_fwd(gpu(bf(qkv)), out, lse, Bn, N, H, dh, probs=probs)
+    got = out.float().cpu().view(Bn, N, H, dh).transpose(1, 2)
+    assert rel_l2(got, t(g["o"])) < 2e-2                          # bf16 inputs vs fp32 reference
+    assert rel_l2(probs, t(g["p"])) < 3e-2
+
+
+def test_attention_rejects_unsupported(ops):
+    from vitssl_hip import _lib as L
+    qkv = torch.zeros(4, 3 * 32, dtype=torch.bfloat16, device=DEV)
+    out = torch.zeros(4, 32, dtype=torch.bfloat16, device=DEV)
+    lse = torch.zeros(1, 1, 4, device=DEV)
+    with pytest.raises(L.VitsslError):
+        ops.attn_fwd(qkv, out, lse, 1, 4, 1, 32)
+
+
+# ----------------------------------------------------------------------------- patch / gather glue
+def test_patch_and_gather_kernels(ops):
+    torch.manual_seed(1)
+    Bn, Cc, Hh, Ww, P = 3, 3, 32, 48, 8
+    img = torch.rand(Bn, Cc, Hh, Ww)
+    ref = O.patchify(img, P).reshape(-1, Cc * P * P)
+    patches = torch.empty(ref.shape, dtype=torch.bfloat16, device=DEV)
+    ops.patchify_bf16(gpu(img), patches, P)
+    assert torch.equal(patches.cpu(), bf(ref))                    # exact: pure gather + RNE cast
+    idx = torch.tensor([0, 5, 7, 23, 24, 70], dtype=torch.int32)
+    out = torch.empty(idx.numel(), Cc * P * P, device=DEV)
+    ops.gather_patches_f32(gpu(img), gpu(idx), out, P)
+    assert torch.equal(out.cpu(), ref[idx.long()])                # bit-exact fp32 targets
+
+    x = torch.randn(50, 192)
+    rows = torch.tensor([3, 4, 10, 49], dtype=torch.int32)
+    sel = torch.empty(4, 192, dtype=torch.bfloat16, device=DEV)
+    ops.gather_rows_bf16(gpu(x), gpu(rows), sel)
+    assert torch.equal(sel.cpu(), bf(x[rows.long()]))
+    inv = torch.full((50,), -1, dtype=torch.int32)
+    inv[rows.long()] = torch.arange(4, dtype=torch.int32)
+    g = torch.full((50, 192), 5.0, device=DEV)
+    ops.scatter_rows_f32(sel, gpu(inv), g)
+    refg = torch.zeros(50, 192)
+    refg[rows.long()] = sel.float().cpu()
+    assert torch.equal(g.cpu(), refg)
+
+    Bq, T, D = 4, 17, 64
+    xx = torch.randn(Bq * T, D)
+    cls = torch.empty(Bq, D, device=DEV)
+    ops.gather_cls_f32(gpu(xx), cls, Bq, T, D)
+    assert torch.equal(cls.cpu(), xx.view(Bq, T, D)[:, 0])
+    gg = torch.full((Bq * T, D), 3.0, device=DEV)
+    ops.scatter_cls_f32(cls, gg, Bq, T, D)
+    refgg = torch.zeros(Bq, T, D)
+    refgg[:, 0] = cls.cpu()
+    assert torch.equal(gg.cpu().view(Bq, T, D), refgg)
+
+
+@pytest.mark.parametrize("tok_offset,use_mask", [(0, True), (1, False)])
+def test_embed_bwd(ops, tok_offset, use_mask):
+    torch.manual_seed(2)
+    Bn, tokens, D = 5, 16, 128
+    T_out = tokens + tok_offset
+    dtok = torch.randn(Bn * T_out, D)
+    mask = (torch.rand(Bn * tokens) < 0.6).to(torch.uint8) if use_mask else None
+    dproj = torch.empty(Bn * tokens, D, dtype=torch.bfloat16, device=DEV)
+    dpos = torch.zeros(T_out, D, device=DEV)
+    dmt = torch.zeros(D, device=DEV)
+    dbias = torch.zeros(D, device=DEV)
+    dcls = torch.zeros(D, device=DEV)
+    ops.embed_bwd(gpu(dtok), None if mask is None else gpu(mask), dproj, dpos, dmt if use_mask else None, dbias,
+                  dcls if tok_offset else None, Bn, tokens, tok_offset, D)
+    d3 = dtok.view(Bn, T_out, D)
+    assert rel_l2(dpos, d3.sum(0)) < 1e-5
+    patch_rows = d3[:, tok_offset:].reshape(Bn * tokens, D)
+    if use_mask:
+        mb = mask.bool()
+        assert rel_l2(dmt, patch_rows[mb].sum(0)) < 1e-5
+        assert rel_l2(dbias, patch_rows[~mb].sum(0)) < 1e-5
+        ref = patch_rows.clone()
+        ref[mb] = 0
+    else:
+        assert rel_l2(dbias, patch_rows.sum(0)) < 1e-5
+        ref = patch_rows
+    assert torch.equal(dproj.cpu(), bf(ref))
+    if tok_offset:
+        assert rel_l2(dcls, d3[:, 0].sum(0)) < 1e-5
+
+
+# ----------------------------------------------------------------------------- losses
+def test_l1_loss(ops):
+    torch.manual_seed(3)
+    pred = torch.randn(117 * 3, 192)
+    tgt = torch.rand(117 * 3, 192)
+    pred[0, :4] = tgt[0, :4]                                      # exact ties -> zero gradient
+    loss = torch.zeros(1, device=DEV)
+    dpred = torch.empty(pred.shape, dtype=torch.bfloat16, device=DEV)
+    n = pred.numel()
+    ops.l1_loss(gpu(pred), gpu(tgt), loss, dpred, gscale=1.0 / n)
+    assert abs(float(loss) / n - float(O.l1_loss_mean(pred, tgt))) < 1e-6
+    ref = torch.sign(pred - tgt) / n
+    assert torch.equal(dpred.cpu(), bf(ref))
+
+
+def test_cross_entropy(ops):
+    torch.manual_seed(4)
+    Bn, Cn = 33, 10
+    logits = torch.randn(Bn, Cn) * 3
+    labels = torch.randint(0, Cn, (Bn,))
+    leaf = logits.clone().requires_grad_(True)
+    ref = O.cross_entropy_mean(leaf, labels)
+    ref.backward()
+    loss = torch.zeros(1, device=DEV)
+    dl = torch.empty(Bn, Cn, dtype=torch.bfloat16, device=DEV)
+    ops.cross_entropy(gpu(logits), gpu(labels), loss, dl, gscale=1.0 / Bn)
+    assert abs(float(loss) / Bn - float(ref)) < 1e-5
+    close_bf16(dl, bf(leaf.grad), atol=1e-4, what="ce grad")
+
+
+# ----------------------------------------------------------------------------- parameter plumbing
+def test_casts(ops):
+    torch.manual_seed(5)
+    for R, Cn in ((768, 2304), (100, 37), (65, 64)):
+        src = torch.randn(R, Cn)
+        dst = torch.empty(R, Cn, dtype=torch.bfloat16, device=DEV)
+        dst_t = torch.empty(Cn, R, dtype=torch.bfloat16, device=DEV)
+        ops.cast_transpose_bf16(gpu(src), dst, dst_t)
+        assert torch.equal(dst.cpu(), bf(src)) and torch.equal(dst_t.cpu(), bf(src).t())
+    v = torch.randn(1003)
+    d = torch.empty(1003, dtype=torch.bfloat16, device=DEV)
+    ops.cast_bf16(gpu(v), d)
+    assert torch.equal(d.cpu(), bf(v))
+    nan = torch.tensor([float("nan"), float("inf"), -0.0, 1e-40] * 2)
+    d8 = torch.empty(8, dtype=torch.bfloat16, device=DEV)
+    ops.cast_bf16(gpu(nan), d8)
+    assert torch.isnan(d8[0]) and torch.isinf(d8[1])              # NaN stays NaN (plain cast, not bit tricks)
+
+
+def test_adamw_matches_torch_golden(ops):
+    g = load_golden("adamw")
+    p = gpu(t(g["params"][0]).clone())
+    m = torch.zeros_like(p)
+    v = torch.zeros_like(p)
+    for i in range(g["grads"].shape[0]):
+        ops.adamw(p, gpu(t(g["grads"][i])), m, v, float(g["lr"]), 0.9, 0.999, 1e-8, float(g["wd"]), i + 1)
+        assert max_abs(p, t(g["params"][i + 1])) < 2e-6
+    # gscale folds the 1/world_size averaging
+    p1, p2 = gpu(torch.ones(64)), gpu(torch.ones(64))
+    gg = gpu(torch.randn(64))
+    z = lambda: torch.zeros(64, device=DEV)
+    ops.adamw(p1, gg * 0.5, z(), z(), 1e-2, 0.9, 0.999, 1e-8, 0.0, 1)
+    ops.adamw(p2, gg, z(), z(), 1e-2, 0.9, 0.999, 1e-8, 0.0, 1, gscale=0.5)
+    assert max_abs(p1, p2) < 1e-7
+
+
+def test_ema(ops):
+    torch.manual_seed(6)
+    tt, ss = torch.randn(1001), torch.randn(1001)
+    td = gpu(tt.clone())
+    ops.ema(td, gpu(ss), 0.996)
+    assert max_abs(td, O.ema_update(tt, ss, 0.996)) < 1e-6

@@ -32,7 +32,7 @@ def test_sdpa_and_block():
     sd = split_prefix(g, "blk_sd/")
     leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     x = t(g["blk_x"]).clone().requires_grad_(True)
-    y, probs = O.encoder_block(x, leaves, "", 4, return_attn=True)
+    y, probs = O.encoder_block(x, leaves, "", 2, return_attn=True)
     assert rel_l2(y, t(g["blk_y"])) < TOL
     assert rel_l2(probs, t(g["blk_probs"])) < TOL
     y.square().sum().backward()

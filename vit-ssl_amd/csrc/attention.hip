@@ -1,0 +1,445 @@
+// Fused multi-head self-attention for ViT-sized sequences (N <= 256, dh = 64), gfx950.
+//
+// The reference materialises S = QK^T / sqrt(dk), softmax, P.V as four passes over a
+// [B,H,N,N] tensor (vit_core/attention.py:20-23).  Here one workgroup owns one
+// (batch, head): K and V (forward) live in LDS for the whole head, the score row of
+// every query is held in registers (N <= 256 keys = 16 accumulators), so the softmax
+// is a plain in-register row reduction (no online rescaling needed).
+//
+// MFMA orientation (v_mfma_f32_16x16x32_bf16; D[i][j], lane holds D[4*(lane>>4)+r][lane&15]):
+//   forward / dQ : S^T[key][q] = K.Q^T   -> a lane holds one query column, its keys in
+//                  registers; the accumulators are directly the B operand of the next
+//                  product that contracts over keys (O^T = V^T.P^T, dQ^T = K^T.dS^T).
+//   dK/dV        : S[q][key]   = Q.K^T   -> key on the lane, queries in registers; the
+//                  accumulators are the B operand of dV^T = dO^T.P and dK^T = Q^T.dS.
+// The contraction index inside a 32-deep MFMA step is permuted consistently on both
+// operands (element jj of lane group g <-> row 16*(jj>>2) + 4g + (jj&3) of the step), so
+// an accumulator tile never moves between lanes.
+//
+// One LDS image per tile serves row reads (ds_read_b128) and transposed reads
+// (ds_read_b64_tr_b16): 128-byte rows, 16-byte chunk index XORed with ((row>>1)&3)<<1;
+// both read kinds are bank-conflict free.
+//
+// Backward = 3 launches: delta = rowsum(dO*O); dK/dV (each wave owns 32 keys, sweeps
+// queries); dQ (each wave owns 16-query tiles, sweeps keys).  P is recomputed from the
+// saved log-sum-exp; nothing of size N^2 ever reaches HBM.
+#include "common.h"
+
+namespace {
+
+constexpr int DH = 64;
+constexpr int ROWB = DH * 2;  // bytes per tile row
+
+__device__ __forceinline__ int tile_off(int row, int ch16) { return row * ROWB + ((ch16 ^ (((row >> 1) & 3) << 1)) << 4); }
+
+// cooperative load of X[n][0..63] (n < N, row stride `stride` elements) into a swizzled LDS tile of Np rows
+__device__ __forceinline__ void load_tile(char* lds, const bf16_t* g, long long stride, int N, int Np, int tid, int nthreads) {
+  for (int idx = tid; idx < Np * 8; idx += nthreads) {
+    const int row = idx >> 3, ch = idx & 7;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (row < N) v = *(const u32x4*)(g + (long long)row * stride + ch * 8);
+    *(u32x4*)(lds + tile_off(row, ch)) = v;
+  }
+}
+
+// natural fragment (8 consecutive d) of row `row`, k-step kk, from an LDS tile
+__device__ __forceinline__ bf16x8 lds_frag(const char* tile, int row, int kk, int lane) {
+  return *(const bf16x8*)(tile + tile_off(row, 4 * kk + (lane >> 4)));
+}
+// natural fragment straight from global (zero past N)
+__device__ __forceinline__ bf16x8 glb_frag(const bf16_t* g, long long stride, int row, int kk, int N, int lane) {
+  u32x4 v = {0u, 0u, 0u, 0u};
+  if (row < N) v = *(const u32x4*)(g + (long long)row * stride + 32 * kk + 8 * (lane >> 4));
+  return __builtin_bit_cast(bf16x8, v);
+}
+// transposed fragment for contraction step s (rows 32s..32s+31, permuted order), columns d0..d0+15
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int s, int dt, int lane) {
+  const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  const int r0 = 32 * s + 4 * g + q;
+  const int r1 = r0 + 16;
+  const int ch = 2 * dt;  // 16-B chunk of column d0 = 16*dt; lanes pp>=2 use the odd chunk
+  const char* a0 = tile + tile_off(r0, ch + (pp >> 1)) + 8 * (pp & 1);
+  const char* a1 = tile + tile_off(r1, ch + (pp >> 1)) + 8 * (pp & 1);
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+// accumulator tiles (2s, 2s+1) -> B-operand fragment of contraction step s
+__device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
+  u32x4 w = {pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]), pack_bf2(b[0], b[1]), pack_bf2(b[2], b[3])};
+  return __builtin_bit_cast(bf16x8, w);
+}
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+
+// ------------------------------------------------------------------ forward
+// grid = B*H, 256 threads.  NS = number of 32-key steps (Np = 32*NS >= N).
+template <int NS>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                       float* __restrict__ lse, float* __restrict__ probs, int N, int H) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int Np = 32 * NS;
+  constexpr int NKT = 2 * NS;
+  char* Kt = smem;
+  char* Vt = smem + Np * ROWB;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const long long stride = 3LL * H * DH;
+  const bf16_t* qg = qkv + (long long)b * N * stride + h * DH;
+  const bf16_t* kg = qg + (long long)H * DH;
+  const bf16_t* vg = kg + (long long)H * DH;
+  load_tile(Kt, kg, stride, N, Np, threadIdx.x, 256);
+  load_tile(Vt, vg, stride, N, Np, threadIdx.x, 256);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const float scale = 0.125f;  // 1/sqrt(64)
+  const int nqt = (N + 15) >> 4;
+
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int q = qt * 16 + li;
+    const bf16x8 q0 = glb_frag(qg, stride, q, 0, N, lane);
+    const bf16x8 q1 = glb_frag(qg, stride, q, 1, N, lane);
+    f32x4 s[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      a = MFMA16(lds_frag(Kt, kt * 16 + li, 0, lane), q0, a);
+      a = MFMA16(lds_frag(Kt, kt * 16 + li, 1, lane), q1, a);
+      s[kt] = a;
+    }
+    // row softmax over keys: registers, then the 4 lane groups (xor 16, 32)
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + 4 * g + r;
+        s[kt][r] = key < N ? s[kt][r] * scale : -INFINITY;
+        m = fmaxf(m, s[kt][r]);
+      }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s[kt][r] = __expf(s[kt][r] - m);
+        sum += s[kt][r];
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) s[kt] *= inv;
+    if (q < N) {
+      if (g == 0) lse[((long long)b * H + h) * N + q] = m + __logf(sum);
+      if (probs) {
+        float* pr = probs + (((long long)b * H + h) * N + q) * N;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kt * 16 + 4 * g + r;
+            if (key < N) pr[key] = s[kt][r];
+          }
+      }
+    }
+    // O^T[d][q] = sum_key V[key][d] P[q][key]
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      const bf16x8 pf = pack_frag(s[2 * st], s[2 * st + 1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[dt] = MFMA16(tr_frag(Vt, st, dt, lane), pf, o[dt]);
+    }
+    if (q < N) {
+      bf16_t* og = out + ((long long)b * N + q) * (H * DH) + h * DH;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        u32x2 w = {pack_bf2(o[dt][0], o[dt][1]), pack_bf2(o[dt][2], o[dt][3])};
+        *(u32x2*)(og + dt * 16 + 4 * g) = w;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ backward: delta
+__global__ void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, float* __restrict__ delta,
+                                  int B, int N, int H) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // (b, q, h)
+  const long long total = (long long)B * N * H;
+  if (idx >= total) return;
+  const int h = (int)(idx % H);
+  const long long bq = idx / H;
+  const int q = (int)(bq % N);
+  const long long b = bq / N;
+  const u32x4* po = (const u32x4*)(o + idx * DH);
+  const u32x4* pd = (const u32x4*)(dout + idx * DH);
+  float acc = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const u32x4 a = po[c], d = pd[c];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) acc += bf_lo(a[w]) * bf_lo(d[w]) + bf_hi(a[w]) * bf_hi(d[w]);
+  }
+  delta[(b * H + h) * N + q] = acc;
+}
+
+// ------------------------------------------------------------------ backward: dK, dV
+// grid = B*H, 512 threads: wave w owns keys [32w, 32w+32).  Q and dO tiles in LDS.
+template <int NS>
+__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                           const float* __restrict__ lse, const float* __restrict__ delta,
+                                                           bf16_t* __restrict__ dqkv, int N, int H) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int Np = 32 * NS;
+  char* Qt = smem;
+  char* Dt = smem + Np * ROWB;
+  float* lse_s = (float*)(smem + 2 * Np * ROWB);
+  float* del_s = lse_s + Np;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const long long stride = 3LL * H * DH;
+  const bf16_t* qg = qkv + (long long)b * N * stride + h * DH;
+  const bf16_t* kg = qg + (long long)H * DH;
+  const bf16_t* vg = kg + (long long)H * DH;
+  const bf16_t* dog = dout + (long long)b * N * (H * DH) + h * DH;
+  load_tile(Qt, qg, stride, N, Np, threadIdx.x, 512);
+  load_tile(Dt, dog, (long long)H * DH, N, Np, threadIdx.x, 512);
+  for (int i = threadIdx.x; i < Np; i += 512) {
+    // padded queries: lse = +inf makes p = exp(0 - inf) = 0
+    lse_s[i] = i < N ? lse[((long long)b * H + h) * N + i] : INFINITY;
+    del_s[i] = i < N ? delta[((long long)b * H + h) * N + i] : 0.f;
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wave * 32 >= N) return;  // wave-uniform; no barrier below
+  const int g = lane >> 4, li = lane & 15;
+  const float scale = 0.125f;
+
+  bf16x8 kf[2][2], vf[2][2];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int key = wave * 32 + kt * 16 + li;
+      kf[kt][kk] = glb_frag(kg, stride, key, kk, N, lane);
+      vf[kt][kk] = glb_frag(vg, stride, key, kk, N, lane);
+    }
+  f32x4 dv[4][2], dk[4][2];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      dv[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dk[dt][kt] = dv[dt][kt];
+    }
+
+#pragma unroll 1
+  for (int qs = 0; qs < NS; ++qs) {
+    f32x4 p[2][2], ds[2][2];  // [query tile in step][key tile]
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int qrow = qs * 32 + t * 16 + li;
+      const bf16x8 qa0 = lds_frag(Qt, qrow, 0, lane), qa1 = lds_frag(Qt, qrow, 1, lane);
+      const bf16x8 da0 = lds_frag(Dt, qrow, 0, lane), da1 = lds_frag(Dt, qrow, 1, lane);
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
+        a = MFMA16(qa0, kf[kt][0], a);
+        a = MFMA16(qa1, kf[kt][1], a);
+        c = MFMA16(da0, vf[kt][0], c);
+        c = MFMA16(da1, vf[kt][1], c);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qq = qs * 32 + t * 16 + 4 * g + r;
+          const float pv = __expf(a[r] * scale - lse_s[qq]);
+          p[t][kt][r] = pv;
+          ds[t][kt][r] = pv * (c[r] - del_s[qq]) * scale;
+        }
+      }
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      const bf16x8 pf = pack_frag(p[0][kt], p[1][kt]);
+      const bf16x8 sf = pack_frag(ds[0][kt], ds[1][kt]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        dv[dt][kt] = MFMA16(tr_frag(Dt, qs, dt, lane), pf, dv[dt][kt]);
+        dk[dt][kt] = MFMA16(tr_frag(Qt, qs, dt, lane), sf, dk[dt][kt]);
+      }
+    }
+  }
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) {
+    const int key = wave * 32 + kt * 16 + li;
+    if (key < N) {
+      bf16_t* dkg = dqkv + ((long long)b * N + key) * stride + (long long)H * DH + h * DH;
+      bf16_t* dvg = dkg + (long long)H * DH;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        u32x2 wk = {pack_bf2(dk[dt][kt][0], dk[dt][kt][1]), pack_bf2(dk[dt][kt][2], dk[dt][kt][3])};
+        u32x2 wv = {pack_bf2(dv[dt][kt][0], dv[dt][kt][1]), pack_bf2(dv[dt][kt][2], dv[dt][kt][3])};
+        *(u32x2*)(dkg + dt * 16 + 4 * g) = wk;
+        *(u32x2*)(dvg + dt * 16 + 4 * g) = wv;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ backward: dQ
+// grid = B*H, 256 threads: waves own 16-query tiles; K and V tiles in LDS.
+template <int NS>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                          const float* __restrict__ lse, const float* __restrict__ delta,
+                                                          bf16_t* __restrict__ dqkv, int N, int H) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int Np = 32 * NS;
+  constexpr int NKT = 2 * NS;
+  char* Kt = smem;
+  char* Vt = smem + Np * ROWB;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const long long stride = 3LL * H * DH;
+  const bf16_t* qg = qkv + (long long)b * N * stride + h * DH;
+  const bf16_t* kg = qg + (long long)H * DH;
+  const bf16_t* vg = kg + (long long)H * DH;
+  const bf16_t* dog = dout + (long long)b * N * (H * DH) + h * DH;
+  load_tile(Kt, kg, stride, N, Np, threadIdx.x, 256);
+  load_tile(Vt, vg, stride, N, Np, threadIdx.x, 256);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const float scale = 0.125f;
+  const int nqt = (N + 15) >> 4;
+
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int q = qt * 16 + li;
+    const bf16x8 q0 = glb_frag(qg, stride, q, 0, N, lane), q1 = glb_frag(qg, stride, q, 1, N, lane);
+    const bf16x8 d0 = glb_frag(dog, (long long)H * DH, q, 0, N, lane), d1 = glb_frag(dog, (long long)H * DH, q, 1, N, lane);
+    const float l = q < N ? lse[((long long)b * H + h) * N + q] : INFINITY;
+    const float dl = q < N ? delta[((long long)b * H + h) * N + q] : 0.f;
+    f32x4 ds[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
+      a = MFMA16(lds_frag(Kt, kt * 16 + li, 0, lane), q0, a);
+      a = MFMA16(lds_frag(Kt, kt * 16 + li, 1, lane), q1, a);
+      c = MFMA16(lds_frag(Vt, kt * 16 + li, 0, lane), d0, c);
+      c = MFMA16(lds_frag(Vt, kt * 16 + li, 1, lane), d1, c);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + 4 * g + r;
+        const float pv = key < N ? __expf(a[r] * scale - l) : 0.f;
+        ds[kt][r] = pv * (c[r] - dl) * scale;
+      }
+    }
+    f32x4 dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      const bf16x8 sf = pack_frag(ds[2 * st], ds[2 * st + 1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dq[dt] = MFMA16(tr_frag(Kt, st, dt, lane), sf, dq[dt]);
+    }
+    if (q < N) {
+      bf16_t* dqg = dqkv + ((long long)b * N + q) * stride + h * DH;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        u32x2 w = {pack_bf2(dq[dt][0], dq[dt][1]), pack_bf2(dq[dt][2], dq[dt][3])};
+        *(u32x2*)(dqg + dt * 16 + 4 * g) = w;
+      }
+    }
+  }
+}
+
+template <typename K>
+int ensure_lds(K kernel, int bytes, bool* done, const char* who) {
+  if (*done || bytes <= 48 * 1024) return VITSSL_OK;
+  hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) {
+    vitssl_set_error("%s: cannot raise dynamic LDS: %s", who, hipGetErrorString(e));
+    return VITSSL_ERR_LAUNCH;
+  }
+  *done = true;
+  return VITSSL_OK;
+}
+
+template <int NS>
+int launch_fwd(const bf16_t* qkv, bf16_t* out, float* lse, float* probs, int B, int N, int H, hipStream_t s) {
+  static bool done = false;
+  const int lds = 2 * NS * 32 * ROWB;
+  if (int rc = ensure_lds(attn_fwd_kernel<NS>, lds, &done, "attn_fwd")) return rc;
+  hipLaunchKernelGGL(attn_fwd_kernel<NS>, dim3(B * H), dim3(256), lds, s, qkv, out, lse, probs, N, H);
+  VS_CHECK_LAUNCH("attn_fwd");
+  return VITSSL_OK;
+}
+
+template <int NS>
+int launch_bwd(const bf16_t* qkv, const bf16_t* dout, const float* lse, const float* delta, bf16_t* dqkv, int B, int N,
+               int H, hipStream_t s) {
+  static bool done_kv = false, done_q = false;
+  const int lds_kv = 2 * NS * 32 * ROWB + 2 * NS * 32 * 4;
+  if (int rc = ensure_lds(attn_bwd_dkv_kernel<NS>, lds_kv, &done_kv, "attn_bwd_dkv")) return rc;
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel<NS>, dim3(B * H), dim3(512), lds_kv, s, qkv, dout, lse, delta, dqkv, N, H);
+  VS_CHECK_LAUNCH("attn_bwd_dkv");
+  const int lds_q = 2 * NS * 32 * ROWB;
+  if (int rc = ensure_lds(attn_bwd_dq_kernel<NS>, lds_q, &done_q, "attn_bwd_dq")) return rc;
+  hipLaunchKernelGGL(attn_bwd_dq_kernel<NS>, dim3(B * H), dim3(256), lds_q, s, qkv, dout, lse, delta, dqkv, N, H);
+  VS_CHECK_LAUNCH("attn_bwd_dq");
+  return VITSSL_OK;
+}
+
+#define VS_NS_SWITCH(NSV, CALL)        \
+  switch (NSV) {                       \
+    case 1: return CALL(1);            \
+    case 2: return CALL(2);            \
+    case 3: return CALL(3);            \
+    case 4: return CALL(4);            \
+    case 5: return CALL(5);            \
+    case 6: return CALL(6);            \
+    case 7: return CALL(7);            \
+    default: return CALL(8);           \
+  }
+
+int check_attn_shape(const char* who, int B, int N, int H, int dh) {
+  VS_CHECK_ARG(B > 0 && N > 0 && H > 0, "%s: empty problem B=%d N=%d H=%d", who, B, N, H);
+  VS_CHECK_ARG(dh == DH, "%s: head dim %d unsupported (this build handles dh=64: ViT-Tiny/S/B/L)", who, dh);
+  VS_CHECK_ARG(N <= 256, "%s: sequence length %d > 256 unsupported", who, N);
+  return VITSSL_OK;
+}
+
+}  // namespace
+
+extern "C" int vitssl_attn_fwd(const void* qkv, void* out, float* lse, float* probs, int B, int N, int H, int dh,
+                               void* stream) {
+  VS_CHECK_ARG(qkv && out && lse, "attn_fwd: null pointer");
+  if (int rc = check_attn_shape("attn_fwd", B, N, H, dh)) return rc;
+#define VS_CALL(NS) launch_fwd<NS>((const bf16_t*)qkv, (bf16_t*)out, lse, probs, B, N, H, (hipStream_t)stream)
+  VS_NS_SWITCH((N + 31) / 32, VS_CALL)
+#undef VS_CALL
+}
+
+extern "C" int vitssl_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                               float* delta_ws, int B, int N, int H, int dh, void* stream) {
+  VS_CHECK_ARG(qkv && out && dout && lse && dqkv && delta_ws, "attn_bwd: null pointer");
+  if (int rc = check_attn_shape("attn_bwd", B, N, H, dh)) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const long long total = (long long)B * N * H;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const bf16_t*)out,
+                     (const bf16_t*)dout, delta_ws, B, N, H);
+  VS_CHECK_LAUNCH("attn_delta");
+#define VS_CALL(NS) launch_bwd<NS>((const bf16_t*)qkv, (const bf16_t*)dout, lse, delta_ws, (bf16_t*)dqkv, B, N, H, s)
+  VS_NS_SWITCH((N + 31) / 32, VS_CALL)
+#undef VS_CALL
+}

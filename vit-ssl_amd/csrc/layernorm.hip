@@ -1,0 +1,242 @@
+// LayerNorm forward / backward for the fp32 residual stream (gfx950, HBM-bound).
+//
+// One 64-lane wave per row; the row lives in registers as V float4 per lane
+// (cols <= 256*V), statistics are two-pass in fp32 via wavefront shuffles, the
+// output is emitted as bf16 (the operand of the next MFMA GEMM).
+//
+// Backward fuses, per row: LN input-gradient, + residual-branch gradient, fp32 store
+// of the new residual gradient, and the dropout-masked bf16 copy the next
+// (reverse-order) GEMM consumes; per column: dgamma, dbeta and the bias-gradient
+// column sum are accumulated in registers across the rows a wave visits, reduced
+// across the block's 4 waves in LDS and added to global with one atomic per column
+// per block.
+#include "common.h"
+
+namespace {
+
+constexpr int LN_THREADS = 256;  // 4 waves = 4 rows in flight per block
+
+template <int V>
+__global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd,
+                                                            long long rows, int cols, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int c4n = cols >> 2;
+  f32x4 g[V], b[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    const int c4 = lane + 64 * v;
+    if (c4 < c4n) {
+      g[v] = *(const f32x4*)(gamma + 4 * c4);
+      b[v] = *(const f32x4*)(beta + 4 * c4);
+    }
+  }
+  const float inv = 1.0f / (float)cols;
+  for (long long row = (long long)blockIdx.x * 4 + wave; row < rows; row += (long long)gridDim.x * 4) {
+    const float* xr = x + row * cols;
+    f32x4 xv[V];
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const int c4 = lane + 64 * v;
+      if (c4 < c4n) {
+        xv[v] = *(const f32x4*)(xr + 4 * c4);
+        s += xv[v][0] + xv[v][1] + xv[v][2] + xv[v][3];
+      }
+    }
+    const float mu = wave_sum(s) * inv;
+    float ss = 0.f;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const int c4 = lane + 64 * v;
+      if (c4 < c4n) {
+        xv[v] -= mu;
+        ss += xv[v][0] * xv[v][0] + xv[v][1] * xv[v][1] + xv[v][2] * xv[v][2] + xv[v][3] * xv[v][3];
+      }
+    }
+    const float rs = rsqrtf(wave_sum(ss) * inv + eps);
+    if (lane == 0) {
+      mean[row] = mu;
+      rstd[row] = rs;
+    }
+    bf16_t* yr = y + row * cols;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const int c4 = lane + 64 * v;
+      if (c4 < c4n) {
+        const f32x4 o = xv[v] * rs * g[v] + b[v];
+        u32x2 w = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+        *(u32x2*)(yr + 4 * c4) = w;
+      }
+    }
+  }
+}
+
+// HAS_LN = false turns the kernel into the plain "mask + cast + column-sum" of g_res.
+template <int V, bool HAS_LN>
+__global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, const float* g_res,
+                                                            float* g_out, bf16_t* __restrict__ gm, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, float* __restrict__ gm_colsum,
+                                                            DropKey dk, int drop_on, long long rows, int cols) {
+  __shared__ __attribute__((aligned(16))) float red[4][V * 256];   // [wave][col]
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int c4n = cols >> 2;
+  f32x4 g[V], acc_dg[V], acc_db[V], acc_cs[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    const int c4 = lane + 64 * v;
+    acc_dg[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc_db[v] = acc_dg[v];
+    acc_cs[v] = acc_dg[v];
+    if (HAS_LN && c4 < c4n) g[v] = *(const f32x4*)(gamma + 4 * c4);
+  }
+  const float inv = 1.0f / (float)cols;
+  for (long long row = (long long)blockIdx.x * 4 + wave; row < rows; row += (long long)gridDim.x * 4) {
+    f32x4 dx[V];
+    if constexpr (HAS_LN) {
+      const float mu = mean[row], rs = rstd[row];
+      f32x4 xh[V], dyg[V];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const int c4 = lane + 64 * v;
+        if (c4 < c4n) {
+          const u32x2 w = *(const u32x2*)(dy + row * cols + 4 * c4);
+          const f32x4 d = {bf_lo(w[0]), bf_hi(w[0]), bf_lo(w[1]), bf_hi(w[1])};
+          xh[v] = (*(const f32x4*)(x + row * cols + 4 * c4) - mu) * rs;
+          dyg[v] = d * g[v];
+          acc_dg[v] += d * xh[v];
+          acc_db[v] += d;
+          s1 += dyg[v][0] + dyg[v][1] + dyg[v][2] + dyg[v][3];
+          const f32x4 t = dyg[v] * xh[v];
+          s2 += t[0] + t[1] + t[2] + t[3];
+        }
+      }
+      const float m1 = wave_sum(s1) * inv;
+      const float m2 = wave_sum(s2) * inv;
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const int c4 = lane + 64 * v;
+        if (c4 < c4n) {
+          dx[v] = (dyg[v] - m1 - xh[v] * m2) * rs;
+          if (g_res) dx[v] += *(const f32x4*)(g_res + row * cols + 4 * c4);
+          *(f32x4*)(g_out + row * cols + 4 * c4) = dx[v];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const int c4 = lane + 64 * v;
+        if (c4 < c4n) dx[v] = *(const f32x4*)(g_res + row * cols + 4 * c4);
+      }
+    }
+    if (gm) {
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const int c4 = lane + 64 * v;
+        if (c4 < c4n) {
+          f32x4 o = dx[v];
+          if (drop_on) {
+            float mult[4];
+            drop_mult4(dk, (unsigned long long)(row * cols + 4 * c4) >> 2, mult);
+            o[0] *= mult[0]; o[1] *= mult[1]; o[2] *= mult[2]; o[3] *= mult[3];
+          }
+          u32x2 w = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+          *(u32x2*)(gm + row * cols + 4 * c4) = w;
+          acc_cs[v] += o;
+        }
+      }
+    }
+  }
+  // cross-wave column reduction, one atomic per column per block (LDS buffer reused)
+#pragma unroll
+  for (int qty = 0; qty < 3; ++qty) {
+    if (qty < 2 && !HAS_LN) continue;
+    float* target = qty == 0 ? dgamma : (qty == 1 ? dbeta : gm_colsum);
+    if (!target) continue;   // kernel-argument uniform
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const int c4 = lane + 64 * v;
+      if (c4 < c4n) {
+        const f32x4 a = qty == 0 ? acc_dg[v] : (qty == 1 ? acc_db[v] : acc_cs[v]);
+        *(f32x4*)&red[wave][4 * c4] = a;
+      }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < cols; c += LN_THREADS)
+      atomicAdd(target + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+    __syncthreads();
+  }
+}
+
+inline int ln_grid(long long rows) {
+  long long g = (rows + 3) / 4;
+  if (g > 1024) g = 1024;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+template <bool HAS_LN>
+int launch_ln_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                  const float* g_res, float* g_out, void* gm, float* dgamma, float* dbeta, float* gm_colsum,
+                  vitssl_dropout_t drop, int64_t rows, int cols, hipStream_t s) {
+  DropKey dk = make_drop_key(drop);
+  const int on = dk.thr != 0;
+  const int grid = ln_grid(rows);
+#define VS_LNB(V)                                                                                                     \
+  hipLaunchKernelGGL((ln_bwd_kernel<V, HAS_LN>), dim3(grid), dim3(LN_THREADS), 0, s, (const bf16_t*)dy, x, mean, rstd, \
+                     gamma, g_res, g_out, (bf16_t*)gm, dgamma, dbeta, gm_colsum, dk, on, (long long)rows, cols)
+  if (cols <= 256) VS_LNB(1);
+  else if (cols <= 512) VS_LNB(2);
+  else if (cols <= 768) VS_LNB(3);
+  else if (cols <= 1024) VS_LNB(4);
+  else VS_LNB(8);
+#undef VS_LNB
+  VS_CHECK_LAUNCH("layernorm_bwd");
+  return VITSSL_OK;
+}
+
+}  // namespace
+
+extern "C" int vitssl_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* mean,
+                                    float* rstd, int64_t rows, int cols, float eps, void* stream) {
+  VS_CHECK_ARG(x && gamma && beta && y_bf16 && mean && rstd, "layernorm_fwd: null pointer");
+  VS_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 2048, "layernorm_fwd: cols=%d must be a multiple of 4 and <= 2048", cols);
+  const int grid = ln_grid(rows);
+  hipStream_t s = (hipStream_t)stream;
+#define VS_LNF(V)                                                                                                   \
+  hipLaunchKernelGGL(ln_fwd_kernel<V>, dim3(grid), dim3(LN_THREADS), 0, s, x, gamma, beta, (bf16_t*)y_bf16, mean, rstd, \
+                     (long long)rows, cols, eps)
+  if (cols <= 256) VS_LNF(1);
+  else if (cols <= 512) VS_LNF(2);
+  else if (cols <= 768) VS_LNF(3);
+  else if (cols <= 1024) VS_LNF(4);
+  else VS_LNF(8);
+#undef VS_LNF
+  VS_CHECK_LAUNCH("layernorm_fwd");
+  return VITSSL_OK;
+}
+
+extern "C" int vitssl_layernorm_bwd(const void* dy_bf16, const float* x, const float* mean, const float* rstd,
+                                    const float* gamma, const float* g_res, float* g_out, void* gm_bf16, float* dgamma,
+                                    float* dbeta, float* gm_colsum, vitssl_dropout_t drop, int64_t rows, int cols,
+                                    void* stream) {
+  VS_CHECK_ARG(dy_bf16 && x && mean && rstd && gamma && g_out && dgamma && dbeta, "layernorm_bwd: null pointer");
+  VS_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 2048, "layernorm_bwd: cols=%d must be a multiple of 4 and <= 2048", cols);
+  VS_CHECK_ARG(!gm_colsum || gm_bf16, "layernorm_bwd: gm_colsum without gm_bf16");
+  return launch_ln_bwd<true>(dy_bf16, x, mean, rstd, gamma, g_res, g_out, gm_bf16, dgamma, dbeta, gm_colsum, drop, rows,
+                             cols, (hipStream_t)stream);
+}
+
+extern "C" int vitssl_grad_mask_cast(const float* g, void* gm_bf16, float* gm_colsum, vitssl_dropout_t drop,
+                                     int64_t rows, int cols, void* stream) {
+  VS_CHECK_ARG(g && gm_bf16, "grad_mask_cast: null pointer");
+  VS_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 2048, "grad_mask_cast: cols=%d must be a multiple of 4 and <= 2048", cols);
+  return launch_ln_bwd<false>(nullptr, nullptr, nullptr, nullptr, nullptr, g, nullptr, gm_bf16, nullptr, nullptr,
+                              gm_colsum, drop, rows, cols, (hipStream_t)stream);
+}

@@ -1,0 +1,96 @@
+"""ctypes binding of libvitssl_hip.so (C ABI declared in include/vitssl_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails, this raises."""
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvitssl_hip.so")
+HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "include", "vitssl_hip.h"))
+
+
+class VitsslError(RuntimeError):
+    pass
+
+
+class Dropout(C.Structure):
+    _fields_ = [("p", C.c_float), ("site", C.c_uint32), ("seed", C.c_uint64)]
+
+
+class Embed(C.Structure):
+    _fields_ = [("mask", C.c_void_p), ("mask_token", C.c_void_p), ("pos", C.c_void_p),
+                ("tokens", C.c_int), ("out_tokens", C.c_int), ("tok_offset", C.c_int)]
+
+
+class Gemm(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("M", C.c_int64), ("N", C.c_int), ("K", C.c_int),
+                ("epilogue", C.c_int), ("bias", C.c_void_p), ("aux", C.c_void_p), ("out0", C.c_void_p),
+                ("out1", C.c_void_p), ("colsum", C.c_void_p), ("drop", Dropout), ("embed", Embed)]
+
+
+EPI_BF16, EPI_F32, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_EMBED = range(6)
+
+_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+# name -> argtypes (restype is always int except the two noted)
+PROTOTYPES = {
+    "vitssl_dropout_mask": [_vp, _i64, _i64, Dropout, _vp],
+    "vitssl_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _vp],
+    "vitssl_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, Dropout, _i64, _i, _vp],
+    "vitssl_grad_mask_cast": [_vp, _vp, _vp, Dropout, _i64, _i, _vp],
+    "vitssl_gemm_bf16_nt": [C.POINTER(Gemm), _vp],
+    "vitssl_gemm_bf16_tn": [_vp, _vp, _vp, _i64, _i, _i, _vp],
+    "vitssl_attn_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "vitssl_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "vitssl_patchify_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "vitssl_gather_patches_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "vitssl_gather_rows_bf16": [_vp, _vp, _vp, _i, _i, _vp],
+    "vitssl_scatter_rows_f32": [_vp, _vp, _vp, _i64, _i, _vp],
+    "vitssl_gather_cls_f32": [_vp, _vp, _i, _i, _i, _vp],
+    "vitssl_scatter_cls_f32": [_vp, _vp, _i, _i, _i, _vp],
+    "vitssl_embed_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "vitssl_l1_loss": [_vp, _vp, _vp, _vp, _f, _i64, _vp],
+    "vitssl_cross_entropy": [_vp, _vp, _vp, _vp, _f, _i, _i, _vp],
+    "vitssl_cast_bf16": [_vp, _vp, _i64, _vp],
+    "vitssl_cast_transpose_bf16": [_vp, _vp, _vp, _i, _i, _vp],
+    "vitssl_adamw": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _vp],
+    "vitssl_ema": [_vp, _vp, _i64, _f, _vp],
+}
+
+_lib = None
+
+
+def header_symbols():
+    """Entry points declared in include/vitssl_hip.h (int-returning `vitssl_*` functions)."""
+    with open(HEADER_PATH) as f:
+        txt = f.read()
+    return sorted(set(re.findall(r"\b(vitssl_[a-z0-9_]+)\s*\(", txt)))
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VitsslError(
+            f"{LIB_PATH} not found: the HIP library is not built. Run `python __graft_entry__.py` "
+            "(or __graft_entry__.build()). There is no CPU fallback for the vit_core hot path.")
+    l = C.CDLL(LIB_PATH)
+    l.vitssl_last_error.restype = C.c_char_p
+    l.vitssl_last_error.argtypes = []
+    l.vitssl_version.restype = C.c_int
+    l.vitssl_version.argtypes = []
+    for name, args in PROTOTYPES.items():
+        fn = getattr(l, name)  # AttributeError if the symbol is missing
+        fn.restype = C.c_int
+        fn.argtypes = args
+    _lib = l
+    return l
+
+
+def call(name, *args):
+    l = lib()
+    rc = getattr(l, name)(*args)
+    if rc != 0:
+        raise VitsslError(f"{name} failed ({rc}): {l.vitssl_last_error().decode()}")

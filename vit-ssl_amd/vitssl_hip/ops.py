@@ -1,0 +1,200 @@
+"""Tensor-level wrappers over the C ABI: validate device/dtype/shape/contiguity on the
+host (a wrong shape must never reach a hand-written kernel), then enqueue on torch's
+current stream.  No computation happens in Python and there is no fallback path."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import Dropout, Embed, Gemm, call
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, dtype, name, shape=None):
+    if t is None:
+        raise L.VitsslError(f"{name}: tensor is None")
+    if not t.is_cuda:
+        raise L.VitsslError(f"{name}: expected a CUDA (HIP) tensor, got {t.device}; there is no CPU fallback")
+    if t.dtype != dtype:
+        raise L.VitsslError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise L.VitsslError(f"{name}: tensor must be contiguous")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise L.VitsslError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return C.c_void_p(t.data_ptr())
+
+
+def _opt(t, dtype, name, shape=None):
+    return C.c_void_p(0) if t is None else _chk(t, dtype, name, shape)
+
+
+def make_dropout(p=0.0, seed=0, site=0):
+    return Dropout(float(p), int(site) & 0xFFFFFFFF, int(seed) & 0xFFFFFFFFFFFFFFFF)
+
+
+NO_DROP = make_dropout()
+
+
+def dropout_mask(rows, cols, drop, device):
+    keep = torch.empty(rows, cols, dtype=torch.uint8, device=device)
+    call("vitssl_dropout_mask", _chk(keep, torch.uint8, "keep"), rows, cols, drop, _stream())
+    return keep
+
+
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps=1e-5):
+    rows, cols = x.shape
+    call("vitssl_layernorm_fwd", _chk(x, F32, "x"), _chk(gamma, F32, "gamma", (cols,)), _chk(beta, F32, "beta", (cols,)),
+         _chk(y, BF16, "y", (rows, cols)), _chk(mean, F32, "mean", (rows,)), _chk(rstd, F32, "rstd", (rows,)),
+         rows, cols, float(eps), _stream())
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, g_res, g_out, gm, dgamma, dbeta, gm_colsum=None, drop=NO_DROP):
+    rows, cols = x.shape
+    call("vitssl_layernorm_bwd", _chk(dy, BF16, "dy", (rows, cols)), _chk(x, F32, "x"), _chk(mean, F32, "mean", (rows,)),
+         _chk(rstd, F32, "rstd", (rows,)), _chk(gamma, F32, "gamma", (cols,)), _opt(g_res, F32, "g_res", (rows, cols)),
+         _chk(g_out, F32, "g_out", (rows, cols)), _opt(gm, BF16, "gm", (rows, cols)), _chk(dgamma, F32, "dgamma", (cols,)),
+         _chk(dbeta, F32, "dbeta", (cols,)), _opt(gm_colsum, F32, "gm_colsum", (cols,)), drop, rows, cols, _stream())
+
+
+def grad_mask_cast(g, gm, gm_colsum=None, drop=NO_DROP):
+    rows, cols = g.shape
+    call("vitssl_grad_mask_cast", _chk(g, F32, "g"), _chk(gm, BF16, "gm", (rows, cols)),
+         _opt(gm_colsum, F32, "gm_colsum", (cols,)), drop, rows, cols, _stream())
+
+
+_OUT0_DTYPE = {L.EPI_BF16: BF16, L.EPI_F32: F32, L.EPI_GELU: BF16, L.EPI_RESID: F32, L.EPI_DGELU: BF16, L.EPI_EMBED: F32}
+
+
+def gemm_nt(A, B, out0, epilogue, bias=None, aux=None, out1=None, colsum=None, drop=NO_DROP, embed=None):
+    """out = A[M,K] @ B[N,K]^T with the fused epilogue (see include/vitssl_hip.h)."""
+    M, K = A.shape
+    N, K2 = B.shape
+    if K != K2:
+        raise L.VitsslError(f"gemm_nt: K mismatch {K} vs {K2}")
+    g = Gemm()
+    g.A = _chk(A, BF16, "A")
+    g.B = _chk(B, BF16, "B")
+    g.M, g.N, g.K = M, N, K
+    g.epilogue = epilogue
+    g.bias = _opt(bias, F32, "bias", (N,))
+    if epilogue == L.EPI_EMBED:
+        if embed is None:
+            raise L.VitsslError("gemm_nt: EPI_EMBED needs embed=(mask, mask_token, pos, tokens, out_tokens, tok_offset)")
+        mask, mask_token, pos, tokens, out_tokens, tok_offset = embed
+        if M % tokens != 0:
+            raise L.VitsslError("gemm_nt: M must be a multiple of tokens")
+        e = Embed()
+        e.mask = _opt(mask, torch.uint8, "mask", (M,))
+        e.mask_token = _opt(mask_token, F32, "mask_token", (N,))
+        e.pos = _chk(pos, F32, "pos", (out_tokens, N))
+        e.tokens, e.out_tokens, e.tok_offset = tokens, out_tokens, tok_offset
+        g.embed = e
+        g.out0 = _chk(out0, F32, "out0", ((M // tokens) * out_tokens, N))
+    else:
+        g.out0 = _chk(out0, _OUT0_DTYPE[epilogue], "out0", (M, N))
+    if epilogue == L.EPI_RESID:
+        g.aux = _chk(aux, F32, "aux(residual)", (M, N))
+    elif epilogue == L.EPI_DGELU:
+        g.aux = _chk(aux, BF16, "aux(u)", (M, N))
+    g.out1 = _opt(out1, BF16, "out1", (M, N))
+    g.colsum = _opt(colsum, F32, "colsum", (N,))
+    g.drop = drop
+    call("vitssl_gemm_bf16_nt", C.byref(g), _stream())
+
+
+def gemm_tn(A, B, Cacc):
+    """Cacc[N1,N2] (fp32) += A[M,N1]^T @ B[M,N2]."""
+    M, N1 = A.shape
+    M2, N2 = B.shape
+    if M != M2:
+        raise L.VitsslError(f"gemm_tn: M mismatch {M} vs {M2}")
+    call("vitssl_gemm_bf16_tn", _chk(A, BF16, "A"), _chk(B, BF16, "B"), _chk(Cacc, F32, "C", (N1, N2)), M, N1, N2, _stream())
+
+
+def attn_fwd(qkv, out, lse, B, N, H, dh, probs=None):
+    call("vitssl_attn_fwd", _chk(qkv, BF16, "qkv", (B * N, 3 * H * dh)), _chk(out, BF16, "out", (B * N, H * dh)),
+         _chk(lse, F32, "lse", (B, H, N)), _opt(probs, F32, "probs", (B, H, N, N)), B, N, H, dh, _stream())
+
+
+def attn_bwd(qkv, out, dout, lse, dqkv, delta_ws, B, N, H, dh):
+    call("vitssl_attn_bwd", _chk(qkv, BF16, "qkv", (B * N, 3 * H * dh)), _chk(out, BF16, "out", (B * N, H * dh)),
+         _chk(dout, BF16, "dout", (B * N, H * dh)), _chk(lse, F32, "lse", (B, H, N)),
+         _chk(dqkv, BF16, "dqkv", (B * N, 3 * H * dh)), _chk(delta_ws, F32, "delta_ws", (B, H, N)), B, N, H, dh, _stream())
+
+
+def patchify_bf16(img, patches, P):
+    B, Cc, H, W = img.shape
+    call("vitssl_patchify_bf16", _chk(img, F32, "img"), _chk(patches, BF16, "patches", (B * (H // P) * (W // P), Cc * P * P)),
+         B, Cc, H, W, P, _stream())
+
+
+def gather_patches_f32(img, idx, out, P):
+    B, Cc, H, W = img.shape
+    n = idx.numel()
+    call("vitssl_gather_patches_f32", _chk(img, F32, "img"), _chk(idx, torch.int32, "idx"), _chk(out, F32, "out", (n, Cc * P * P)),
+         n, Cc, H, W, P, _stream())
+
+
+def gather_rows_bf16(x, idx, out):
+    rows, cols = x.shape
+    n = idx.numel()
+    call("vitssl_gather_rows_bf16", _chk(x, F32, "x"), _chk(idx, torch.int32, "idx"), _chk(out, BF16, "out", (n, cols)), n, cols, _stream())
+
+
+def scatter_rows_f32(src, inv, g):
+    rows, cols = g.shape
+    call("vitssl_scatter_rows_f32", _chk(src, BF16, "src"), _chk(inv, torch.int32, "inv", (rows,)), _chk(g, F32, "g"), rows, cols, _stream())
+
+
+def gather_cls_f32(x, out, B, T, D):
+    call("vitssl_gather_cls_f32", _chk(x, F32, "x", (B * T, D)), _chk(out, F32, "out", (B, D)), B, T, D, _stream())
+
+
+def scatter_cls_f32(gcls, g, B, T, D):
+    call("vitssl_scatter_cls_f32", _chk(gcls, F32, "gcls", (B, D)), _chk(g, F32, "g", (B * T, D)), B, T, D, _stream())
+
+
+def embed_bwd(dtok, mask, dproj, dpos, dmask_token, dbias, dcls, B, tokens, tok_offset, D):
+    T_out = tokens + tok_offset
+    call("vitssl_embed_bwd", _chk(dtok, F32, "dtok", (B * T_out, D)), _opt(mask, torch.uint8, "mask", (B * tokens,)),
+         _chk(dproj, BF16, "dproj", (B * tokens, D)), _opt(dpos, F32, "dpos", (T_out, D)),
+         _opt(dmask_token, F32, "dmask_token", (D,)), _opt(dbias, F32, "dbias", (D,)), _opt(dcls, F32, "dcls", (D,)),
+         B, tokens, tok_offset, D, _stream())
+
+
+def l1_loss(pred, target, loss_sum, dpred=None, gscale=0.0):
+    n = pred.numel()
+    call("vitssl_l1_loss", _chk(pred, F32, "pred"), _chk(target, F32, "target", pred.shape), _chk(loss_sum, F32, "loss_sum", (1,)),
+         _opt(dpred, BF16, "dpred", pred.shape), float(gscale), n, _stream())
+
+
+def cross_entropy(logits, labels, loss_sum, dlogits=None, gscale=0.0):
+    B, Cn = logits.shape
+    call("vitssl_cross_entropy", _chk(logits, F32, "logits"), _chk(labels, torch.int64, "labels", (B,)),
+         _chk(loss_sum, F32, "loss_sum", (1,)), _opt(dlogits, BF16, "dlogits", (B, Cn)), float(gscale), B, Cn, _stream())
+
+
+def cast_bf16(src, dst):
+    call("vitssl_cast_bf16", _chk(src, F32, "src"), _chk(dst, BF16, "dst", src.shape), src.numel(), _stream())
+
+
+def cast_transpose_bf16(src, dst, dst_t):
+    R, Cn = src.shape
+    call("vitssl_cast_transpose_bf16", _chk(src, F32, "src"), _opt(dst, BF16, "dst", (R, Cn)), _opt(dst_t, BF16, "dst_t", (Cn, R)),
+         R, Cn, _stream())
+
+
+def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step, gscale=1.0):
+    n = p.numel()
+    call("vitssl_adamw", _chk(p, F32, "p"), _chk(g, F32, "g", p.shape), _chk(m, F32, "m", p.shape), _chk(v, F32, "v", p.shape),
+         n, float(lr), float(beta1), float(beta2), float(eps), float(wd), int(step), float(gscale), _stream())
+
+
+def ema(teacher, student, m):
+    call("vitssl_ema", _chk(teacher, F32, "teacher"), _chk(student, F32, "student", teacher.shape), teacher.numel(), float(m), _stream())
