@@ -162,6 +162,9 @@ int vitssl_l1_loss(const float* pred, const float* target, float* loss_sum, void
 int vitssl_cross_entropy(const float* logits, const int64_t* labels, float* loss_sum, void* dlogits_bf16,
                          float gscale, int B, int C, void* stream);
 
+/* out[cols] (fp32, ACCUMULATED) += column sums of x bf16 [rows, cols] (bias gradients). */
+int vitssl_colsum_bf16(const void* x_bf16, float* out, int64_t rows, int cols, void* stream);
+
 /* ---- parameter plumbing ----------------------------------------------------------- */
 int vitssl_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
 /* dst_t bf16 [C,R] = transpose(src f32 [R,C]) ; dst bf16 [R,C] = src (either may be NULL) */

@@ -274,6 +274,22 @@ __global__ void ema_kernel(float* __restrict__ t, const float* __restrict__ s, l
   }
 }
 
+// out[c] += sum_rows x[r][c]; grid = (col chunks of 256*4, row splits)
+__global__ void colsum_bf16_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, long long rows, int cols) {
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (c >= cols) return;
+  const long long per = (rows + gridDim.y - 1) / gridDim.y;
+  const long long r0 = blockIdx.y * per;
+  const long long r1 = r0 + per < rows ? r0 + per : rows;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (long long r = r0; r < r1; ++r) {
+    const u32x2 w = *(const u32x2*)(x + r * cols + c);
+    acc += f32x4{bf_lo(w[0]), bf_hi(w[0]), bf_lo(w[1]), bf_hi(w[1])};
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) atomicAdd(out + c + k, acc[k]);
+}
+
 inline unsigned stream_grid(long long n4) {
   long long g = (n4 + EW_THREADS - 1) / EW_THREADS;
   if (g > 2048) g = 2048;  // 256 CUs x 8 blocks; grid-stride the rest
@@ -380,6 +396,16 @@ extern "C" int vitssl_cross_entropy(const float* logits, const int64_t* labels, 
   hipLaunchKernelGGL(cross_entropy_kernel, dim3((B + 3) / 4), dim3(EW_THREADS), 0, (hipStream_t)stream, logits,
                      (const long long*)labels, loss_sum, (bf16_t*)dlogits_bf16, gscale, B, C);
   VS_CHECK_LAUNCH("cross_entropy");
+  return VITSSL_OK;
+}
+
+extern "C" int vitssl_colsum_bf16(const void* x_bf16, float* out, int64_t rows, int cols, void* stream) {
+  VS_CHECK_ARG(x_bf16 && out && rows > 0 && cols > 0 && cols % 4 == 0, "colsum_bf16: bad args");
+  int splits = (int)((rows + 127) / 128);
+  if (splits > 512) splits = 512;
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3((cols / 4 + EW_THREADS - 1) / EW_THREADS, splits), dim3(EW_THREADS), 0,
+                     (hipStream_t)stream, (const bf16_t*)x_bf16, out, (long long)rows, cols);
+  VS_CHECK_LAUNCH("colsum_bf16");
   return VITSSL_OK;
 }
 

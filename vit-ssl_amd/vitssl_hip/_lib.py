@@ -52,6 +52,7 @@ PROTOTYPES = {
     "vitssl_embed_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "vitssl_l1_loss": [_vp, _vp, _vp, _vp, _f, _i64, _vp],
     "vitssl_cross_entropy": [_vp, _vp, _vp, _vp, _f, _i, _i, _vp],
+    "vitssl_colsum_bf16": [_vp, _vp, _i64, _i, _vp],
     "vitssl_cast_bf16": [_vp, _vp, _i64, _vp],
     "vitssl_cast_transpose_bf16": [_vp, _vp, _vp, _i, _i, _vp],
     "vitssl_adamw": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _vp],

@@ -1,0 +1,363 @@
+"""Host-side composition of the HIP kernels into the vit_core forward/backward.
+
+Design (MI355X-first, not a translation of the reference's eager module graph):
+  * every parameter of a model lives in ONE flat fp32 buffer (FlatStore) with a
+    matching flat gradient buffer; q/k/v weights are adjacent, so the fused QKV weight
+    [3D, D] and its gradient are free views.  AdamW, EMA and the data-parallel
+    all-reduce operate on the flat buffers (one kernel / few large collectives).
+  * bf16 copies of every GEMM weight, plus the transposed copy the dgrad GEMM reads,
+    are refreshed only when the flat buffer's version changes (once per optimizer step).
+  * activations needed by backward are kept in step-persistent workspaces (288 GB of
+    HBM: nothing is recomputed except dropout masks, which are counter-based).
+  * backward is an explicit reverse schedule (no autograd graph inside the stack), so
+    gradient ranges become ready in a known order and the reducer overlaps their
+    all-reduce with the remaining backward on a side stream.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import _lib as L
+from . import ops
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+ALIGN = 64  # elements; keeps every parameter 256-byte aligned inside the flat buffer
+
+
+def _round_up(n: int, a: int) -> int:
+    return (n + a - 1) // a * a
+
+
+class Workspace:
+    """Named device buffers reused across steps (no allocation in steady state)."""
+
+    def __init__(self):
+        self._bufs: Dict[str, torch.Tensor] = {}
+
+    def get(self, name: str, shape, dtype, device) -> torch.Tensor:
+        t = self._bufs.get(name)
+        shape = tuple(int(s) for s in shape)
+        if t is None or t.shape != shape or t.dtype != dtype or t.device != device:
+            t = torch.empty(shape, dtype=dtype, device=device)
+            self._bufs[name] = t
+        return t
+
+    def clear(self):
+        self._bufs.clear()
+
+
+class FlatStore:
+    """Flat fp32 parameter / gradient buffers behind an nn.Module tree.
+
+    The module keeps ordinary nn.Parameters with the reference's state_dict keys; their
+    storage is re-pointed into `self.flat` (and `.grad` into `self.gflat` on request).
+    """
+
+    def __init__(self, module: nn.Module, device: torch.device, only: Optional[Callable[[str], bool]] = None):
+        self.module = module
+        self.device = device
+        self.names: List[str] = []
+        self.params: List[nn.Parameter] = []
+        self.offsets: Dict[str, Tuple[int, int]] = {}
+        off = 0
+        for name, p in module.named_parameters():
+            if only is not None and not only(name):
+                continue
+            n = p.numel()
+            self.names.append(name)
+            self.params.append(p)
+            self.offsets[name] = (off, n)
+            off = _round_up(off + n, ALIGN)
+        self.numel = off
+        self.flat = torch.zeros(off, dtype=F32, device=device)
+        self.gflat = torch.zeros(off, dtype=F32, device=device)
+        with torch.no_grad():
+            for name, p in zip(self.names, self.params):
+                o, n = self.offsets[name]
+                view = self.flat[o:o + n].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+        self._bf16: Dict[str, torch.Tensor] = {}
+        self._bf16_version = -1
+        self._dirty = True
+        self._cast_jobs: List[Tuple[str, Callable[[], torch.Tensor], bool]] = []
+
+    # ---- bookkeeping -------------------------------------------------------
+    def is_attached(self) -> bool:
+        """True while every Parameter still aliases the flat buffer (a .to()/.cuda() or
+        load with assign=True re-allocates them)."""
+        base = self.flat.data_ptr()
+        for name, p in zip(self.names, self.params):
+            o, _ = self.offsets[name]
+            if p.data_ptr() != base + 4 * o:
+                return False
+        return True
+
+    def view(self, name: str, shape=None) -> torch.Tensor:
+        o, n = self.offsets[name]
+        v = self.flat[o:o + n]
+        return v.view(shape) if shape is not None else v
+
+    def gview(self, name: str, shape=None) -> torch.Tensor:
+        o, n = self.offsets[name]
+        v = self.gflat[o:o + n]
+        return v.view(shape) if shape is not None else v
+
+    def span(self, first: str, last: str) -> Tuple[int, int]:
+        lo = self.offsets[first][0]
+        o, n = self.offsets[last]
+        return lo, o + n
+
+    def span_view(self, first: str, last: str, shape, grad=False) -> torch.Tensor:
+        lo, hi = self.span(first, last)
+        buf = self.gflat if grad else self.flat
+        v = buf[lo:hi]
+        if v.numel() != int(torch.Size(shape).numel()):
+            raise L.VitsslError(f"parameters {first}..{last} are not contiguous in the flat store")
+        return v.view(shape)
+
+    def attach_grads(self):
+        """Make every p.grad a view of the flat gradient buffer (fused-step mode)."""
+        for name, p in zip(self.names, self.params):
+            p.grad = self.gview(name, p.shape)
+
+    def mark_dirty(self):
+        self._dirty = True
+
+    # ---- bf16 weight caches --------------------------------------------------
+    def register_weight(self, key: str, src: Callable[[], torch.Tensor], transposed_too: bool = True):
+        """Declare a 2-D GEMM weight [N,K]; caches `key` (bf16 [N,K]) and, if asked,
+        `key + '.T'` (bf16 [K,N], the operand of the dgrad GEMM)."""
+        self._cast_jobs.append((key, src, transposed_too))
+
+    def refresh_weights(self):
+        ver = self.flat._version
+        if not self._dirty and ver == self._bf16_version and self._bf16:
+            return
+        for key, src, tr in self._cast_jobs:
+            w = src()
+            R, Cn = w.shape
+            dst = self._bf16.get(key)
+            if dst is None or dst.shape != (R, Cn):
+                dst = torch.empty(R, Cn, dtype=BF16, device=self.device)
+                self._bf16[key] = dst
+            dst_t = None
+            if tr:
+                dst_t = self._bf16.get(key + ".T")
+                if dst_t is None or dst_t.shape != (Cn, R):
+                    dst_t = torch.empty(Cn, R, dtype=BF16, device=self.device)
+                    self._bf16[key + ".T"] = dst_t
+            ops.cast_transpose_bf16(w.contiguous(), dst, dst_t)
+        self._bf16_version = self.flat._version
+        self._dirty = False
+
+    def w(self, key: str) -> torch.Tensor:
+        return self._bf16[key]
+
+
+class GradReducer:
+    """Data-parallel gradient averaging over RCCL (torch.distributed 'nccl' on ROCm),
+    overlapped with backward: the engine calls `ready(lo, hi)` as soon as a contiguous
+    range of the flat gradient buffer is final; ranges are coalesced into buckets of
+    >= `bucket_elems` and all-reduced (sum) on a side stream.  The 1/world factor is
+    folded into the optimizer kernel.  On CPU tensors (gloo, tests) it runs inline."""
+
+    def __init__(self, gflat: torch.Tensor, group=None, bucket_mb: float = 32.0):
+        import torch.distributed as dist
+        self.dist = dist
+        self.gflat = gflat
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.bucket_elems = int(bucket_mb * 1024 * 1024 / 4)
+        self.pending: List[Tuple[int, int]] = []
+        self.pending_elems = 0
+        self.handles = []
+        self.cuda = gflat.is_cuda
+        self.comm_stream = torch.cuda.Stream(device=gflat.device) if self.cuda else None
+        self.launched: List[Tuple[int, int]] = []
+
+    def _flush(self):
+        if not self.pending:
+            return
+        # merge adjacent ranges (the backward schedule hands them over high-to-low)
+        rng = sorted(self.pending)
+        merged = [list(rng[0])]
+        for lo, hi in rng[1:]:
+            if lo <= merged[-1][1]:
+                merged[-1][1] = max(merged[-1][1], hi)
+            else:
+                merged.append([lo, hi])
+        self.pending, self.pending_elems = [], 0
+        for lo, hi in merged:
+            self.launched.append((lo, hi))
+            if self.world == 1:
+                continue
+            chunk = self.gflat[lo:hi]
+            if self.cuda:
+                self.comm_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self.comm_stream):
+                    self.dist.all_reduce(chunk, group=self.group)
+            else:
+                self.handles.append(self.dist.all_reduce(chunk, group=self.group, async_op=True))
+
+    def begin(self):
+        self.pending, self.pending_elems, self.handles, self.launched = [], 0, [], []
+
+    def ready(self, lo: int, hi: int):
+        self.pending.append((lo, hi))
+        self.pending_elems += hi - lo
+        if self.pending_elems >= self.bucket_elems:
+            self._flush()
+
+    def finish(self):
+        """Launch what is left and make the compute stream wait for all buckets."""
+        self._flush()
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+        if self.cuda and self.world > 1:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+    @property
+    def grad_scale(self) -> float:
+        return 1.0 / self.world
+
+
+class EncoderStack:
+    """L pre-LN transformer blocks (vit_core/encoder_block.py:40-53) on a flat store."""
+
+    def __init__(self, store: FlatStore, block_prefixes: List[str], D: int, H: int, F: int, p_drop: float,
+                 site_base: int = 0):
+        if D % H != 0:
+            raise AssertionError(f"d_model({D}) must be cleanly divisible by num_heads({H})!")
+        self.store = store
+        self.bp = list(block_prefixes)     # e.g. ["encoder_blocks.0.", ...] or [""] for a lone block
+        self.L, self.D, self.H, self.F = len(self.bp), D, H, F
+        self.dh = D // H
+        self.p = float(p_drop)
+        self.site_base = site_base
+        self.ws = Workspace()
+        self._saved = {}
+        for b in self.bp:
+            a = b + "self_attention."
+            store.register_weight(b + "wqkv", lambda a=a, D=D: store.span_view(a + "w_query.weight", a + "w_value.weight", (3 * D, D)))
+            store.register_weight(b + "wo", lambda a=a: store.view(a + "final_linear.weight", (D, D)))
+            store.register_weight(b + "w1", lambda b=b: store.view(b + "feed_forward.linear_in.weight", (F, D)))
+            store.register_weight(b + "w2", lambda b=b: store.view(b + "feed_forward.linear_out.weight", (D, F)))
+
+    # names ----------------------------------------------------------------
+    def _n(self, i, leaf):
+        return self.bp[i] + leaf
+
+    def block_span(self, i) -> Tuple[int, int]:
+        names = [n for n in self.store.names if n.startswith(self.bp[i])]
+        return self.store.span(names[0], names[-1])
+
+    def _drop(self, i, which, seed, training):
+        if not training or self.p <= 0.0:
+            return ops.NO_DROP
+        return ops.make_dropout(self.p, seed, self.site_base + 3 * i + which)
+
+    # forward ----------------------------------------------------------------
+    def forward(self, x: torch.Tensor, B: int, T: int, training: bool, seed: int, save: bool, slot: str = "a",
+                return_attn: bool = False):
+        """x: fp32 [B*T, D] (left untouched).  Returns (x_out fp32 [B*T, D], probs or None)."""
+        st, D, H, F, dh = self.store, self.D, self.H, self.F, self.dh
+        M = B * T
+        dev = x.device
+        g = self.ws.get
+        probs = None
+        rec = {"B": B, "T": T, "seed": seed, "training": training, "blocks": []}
+        cur = x
+        for i in range(self.L):
+            tag = f"{slot}.{i}." if save else f"{slot}.tmp."
+            h1 = g(tag + "h1", (M, D), BF16, dev)
+            mean1 = g(tag + "mean1", (M,), F32, dev)
+            rstd1 = g(tag + "rstd1", (M,), F32, dev)
+            qkv = g(tag + "qkv", (M, 3 * D), BF16, dev)
+            att = g(tag + "att", (M, D), BF16, dev)
+            lse = g(tag + "lse", (B, H, T), F32, dev)
+            xmid = g(tag + "xmid", (M, D), F32, dev)
+            h2 = g(tag + "h2", (M, D), BF16, dev)
+            mean2 = g(tag + "mean2", (M,), F32, dev)
+            rstd2 = g(tag + "rstd2", (M,), F32, dev)
+            u = g(tag + "u", (M, F), BF16, dev)
+            a = g(tag + "a", (M, F), BF16, dev)
+            # block output: a fresh buffer per block when saving (it is the next block's
+            # LN input), otherwise ping-pong
+            xout = g(f"{slot}.{i}.xout" if save else f"{slot}.tmp.xout{i & 1}", (M, D), F32, dev)
+
+            ops.layernorm_fwd(cur, st.view(self._n(i, "layer_norm1.weight")), st.view(self._n(i, "layer_norm1.bias")), h1, mean1, rstd1)
+            ops.gemm_nt(h1, st.w(self._n(i, "wqkv")), qkv, L.EPI_BF16)
+            if return_attn and i == self.L - 1:
+                probs = torch.empty(B, H, T, T, dtype=F32, device=dev)
+            ops.attn_fwd(qkv, att, lse, B, T, H, dh, probs=probs if i == self.L - 1 else None)
+            ops.gemm_nt(att, st.w(self._n(i, "wo")), xmid, L.EPI_RESID, aux=cur, drop=self._drop(i, 0, seed, training))
+            ops.layernorm_fwd(xmid, st.view(self._n(i, "layer_norm2.weight")), st.view(self._n(i, "layer_norm2.bias")), h2, mean2, rstd2)
+            ops.gemm_nt(h2, st.w(self._n(i, "w1")), u, L.EPI_GELU, bias=st.view(self._n(i, "feed_forward.linear_in.bias")),
+                        out1=a, drop=self._drop(i, 1, seed, training))
+            ops.gemm_nt(a, st.w(self._n(i, "w2")), xout, L.EPI_RESID, bias=st.view(self._n(i, "feed_forward.linear_out.bias")),
+                        aux=xmid, drop=self._drop(i, 2, seed, training))
+            if save:
+                rec["blocks"].append(dict(xin=cur, h1=h1, mean1=mean1, rstd1=rstd1, qkv=qkv, att=att, lse=lse, xmid=xmid,
+                                          h2=h2, mean2=mean2, rstd2=rstd2, u=u, a=a))
+            cur = xout
+        if save:
+            self._saved[slot] = rec
+        return cur, probs
+
+    # backward ---------------------------------------------------------------
+    def backward(self, g: torch.Tensor, slot: str = "a", reducer: Optional[GradReducer] = None) -> torch.Tensor:
+        """g: fp32 [M, D] gradient wrt the stack output (overwritten in place; returned
+        holding the gradient wrt the stack input).  Parameter gradients are ACCUMULATED
+        into the store's flat gradient buffer."""
+        st, D, H, F, dh = self.store, self.D, self.H, self.F, self.dh
+        rec = self._saved[slot]
+        B, T, seed, training = rec["B"], rec["T"], rec["seed"], rec["training"]
+        M = B * T
+        dev = g.device
+        w = self.ws.get
+        gm = w("bwd.gm", (M, D), BF16, dev)
+        du = w("bwd.du", (M, F), BF16, dev)
+        dh_ = w("bwd.dh", (M, D), BF16, dev)
+        dqkv = w("bwd.dqkv", (M, 3 * D), BF16, dev)
+        delta = w("bwd.delta", (B, H, T), F32, dev)
+        gv = st.gview
+        last = self.L - 1
+        # top of the chain: dropout-mask + cast of g, and the last block's linear_out bias grad
+        ops.grad_mask_cast(g, gm, gv(self._n(last, "feed_forward.linear_out.bias")), self._drop(last, 2, seed, training))
+        for i in range(last, -1, -1):
+            s = rec["blocks"][i]
+            a_ = self.bp[i] + "self_attention."
+            # MLP
+            ops.gemm_nt(gm, st.w(self._n(i, "w2") + ".T"), du, L.EPI_DGELU, aux=s["u"],
+                        colsum=gv(self._n(i, "feed_forward.linear_in.bias")), drop=self._drop(i, 1, seed, training))
+            ops.gemm_tn(gm, s["a"], gv(self._n(i, "feed_forward.linear_out.weight"), (D, F)))
+            ops.gemm_nt(du, st.w(self._n(i, "w1") + ".T"), dh_, L.EPI_BF16)
+            ops.gemm_tn(du, s["h2"], gv(self._n(i, "feed_forward.linear_in.weight"), (F, D)))
+            ops.layernorm_bwd(dh_, s["xmid"], s["mean2"], s["rstd2"], st.view(self._n(i, "layer_norm2.weight")), g, g, gm,
+                              gv(self._n(i, "layer_norm2.weight")), gv(self._n(i, "layer_norm2.bias")), None,
+                              self._drop(i, 0, seed, training))
+            # attention
+            ops.gemm_nt(gm, st.w(self._n(i, "wo") + ".T"), dh_, L.EPI_BF16)
+            ops.gemm_tn(gm, s["att"], gv(a_ + "final_linear.weight", (D, D)))
+            ops.attn_bwd(s["qkv"], s["att"], dh_, s["lse"], dqkv, delta, B, T, H, dh)
+            ops.gemm_nt(dqkv, st.w(self._n(i, "wqkv") + ".T"), dh_, L.EPI_BF16)
+            ops.gemm_tn(dqkv, s["h1"], st.span_view(a_ + "w_query.weight", a_ + "w_value.weight", (3 * D, D), grad=True))
+            if i > 0:
+                ops.layernorm_bwd(dh_, s["xin"], s["mean1"], s["rstd1"], st.view(self._n(i, "layer_norm1.weight")), g, g, gm,
+                                  gv(self._n(i, "layer_norm1.weight")), gv(self._n(i, "layer_norm1.bias")),
+                                  gv(self._n(i - 1, "feed_forward.linear_out.bias")), self._drop(i - 1, 2, seed, training))
+            else:
+                ops.layernorm_bwd(dh_, s["xin"], s["mean1"], s["rstd1"], st.view(self._n(i, "layer_norm1.weight")), g, g, None,
+                                  gv(self._n(i, "layer_norm1.weight")), gv(self._n(i, "layer_norm1.bias")), None, ops.NO_DROP)
+            if reducer is not None:
+                # every gradient of block i is final, except linear_out.bias of block i-1,
+                # which belongs to the next (lower) range
+                lo, hi = self.block_span(i)
+                reducer.ready(lo, hi)
+        return g

@@ -180,6 +180,11 @@ def cross_entropy(logits, labels, loss_sum, dlogits=None, gscale=0.0):
          _chk(loss_sum, F32, "loss_sum", (1,)), _opt(dlogits, BF16, "dlogits", (B, Cn)), float(gscale), B, Cn, _stream())
 
 
+def colsum_bf16(x, out):
+    rows, cols = x.shape
+    call("vitssl_colsum_bf16", _chk(x, BF16, "x"), _chk(out, F32, "out", (cols,)), rows, cols, _stream())
+
+
 def cast_bf16(src, dst):
     call("vitssl_cast_bf16", _chk(src, F32, "src"), _chk(dst, BF16, "dst", src.shape), src.numel(), _stream())
 

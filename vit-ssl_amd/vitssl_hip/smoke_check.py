@@ -1,0 +1,42 @@
+"""One tiny SimMIM train step on the GPU, checked against the CPU oracle (used by
+__graft_entry__.smoke(); imports oracle/ as the checker only)."""
+import os
+import sys
+
+import torch
+
+_ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+for p in (_ROOT, os.path.join(_ROOT, "vit-ssl_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def run(device):
+    from oracle import vit_oracle as O
+    from vit_core.ssl.simmim import SimMIMViT
+    from vit_core.ssl.simmim.masking import draw_mask
+    from vitssl_hip.optim import FusedAdamW
+
+    torch.manual_seed(42)
+    B, img, P, D, H, F, Lb = 4, 64, 16, 128, 2, 256, 2
+    model = SimMIMViT(num_blocks=Lb, input_shape=(3, img, img), embed_dim=D, patch_size=P, num_heads=H, mlp_dim=F,
+                      dropout=0.0, mask_ratio=0.6)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(device).train()
+    x = torch.rand(B, 3, img, img)
+    mask = draw_mask(B, (img // P) ** 2, 0.6)
+    opt = FusedAdamW(model.flat_store(), lr=1e-4, weight_decay=1e-3)
+    loss = float(model.train_step(x.to(device), opt, mask_cpu=mask))
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    pred, tgt = O.simmim_forward(leaves, x, mask, P, H)
+    ref = O.l1_loss_mean(pred, tgt)
+    ref.backward()
+    assert abs(loss - float(ref)) < 1e-2 * float(ref), (loss, float(ref))
+    st = model.flat_store()
+    worst = 0.0
+    for k in st.names:
+        a, b = st.gview(k).cpu().double(), leaves[k].grad.reshape(-1).double()
+        worst = max(worst, float((a - b).norm() / (b.norm() + 1e-30)))
+    assert worst < 6e-2, worst
+    assert torch.equal(model.last_targets.cpu(), tgt)
+    print(f"smoke: loss {loss:.6f} (oracle {float(ref):.6f}), worst grad rel-L2 {worst:.3e}")
