@@ -71,12 +71,14 @@ def test_simmim_fused_step_equals_autograd_path_and_oracle():
     ref = split_prefix(g, "grad/")
     for k in st.names:
         assert rel_l2(st.gview(k), ref[k].reshape(-1)) < 5e-2, k
-    # one AdamW step on the oracle side, from the reference's exact gradients
+    # the flat AdamW kernel applied exactly one torch.optim.AdamW step to every parameter,
+    # from the gradients the engine produced (gradient parity is asserted above; Adam's
+    # first step is lr*sign(g), so it is checked against the engine's own gradients)
     for k, p in model.named_parameters():
-        want, _, _ = O.adamw_step(sd[k], ref[k], torch.zeros_like(sd[k]), torch.zeros_like(sd[k]), 1, 1e-3, wd=1e-3)
-        # Adam's first step is lr * sign(g): compare where the gradient is not ~0
-        big = ref[k].abs() > 1e-3 * ref[k].abs().max()
-        assert max_abs(p.detach().cpu()[big], want[big]) < 2e-4, k
+        got_g = st.gview(k).cpu().view(sd[k].shape)
+        want, _, _ = O.adamw_step(sd[k], got_g, torch.zeros_like(sd[k]), torch.zeros_like(sd[k]), 1, 1e-3, wd=1e-3)
+        nz = got_g.abs() > 1e-7          # eps matters only for ~zero gradients
+        assert max_abs(p.detach().cpu()[nz], want[nz]) < 2e-6, k
     # second step runs on the refreshed bf16 weights and a fresh mask
     loss2 = model.train_step(x, opt)
     assert torch.isfinite(loss2)

@@ -362,11 +362,10 @@ def mha_apply(query, key, value, wq, wk, wv, wo, H, return_attn=False):
 # --------------------------------------------------------------------------- encoder stack
 class _StackFn(Function):
     @staticmethod
-    def forward(ctx, runner, x, training, return_attn, *params):
+    def forward(ctx, runner, x, training, return_attn, need, *params):
         Bn, T, D = x.shape
         st = runner.store
         st.refresh_weights()
-        need = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
         seed = R.next_seed() if (training and runner.stack.p > 0) else 0
         slot = runner.next_slot() if need else "nograd"
         y, probs = runner.stack.forward(R.as_f32(x).reshape(Bn * T, D), Bn, T, training, seed, save=need, slot=slot,
@@ -388,7 +387,7 @@ class _StackFn(Function):
         g = runner.stack.backward(g, slot=ctx.slot)
         runner.release_slot(ctx.slot)
         grads = [st.gview(n, p.shape).clone() if p.requires_grad else None for n, p in zip(st.names, st.params)]
-        return (None, g.view(Bn, T, D), None, None, *grads)
+        return (None, g.view(Bn, T, D), None, None, None, *grads)
 
 
 class StackRunner:
@@ -412,7 +411,8 @@ class StackRunner:
         pass
 
     def __call__(self, x, training, return_attn=False):
-        y, p = _StackFn.apply(self, x, training, return_attn, *self.store.params)
+        need = torch.is_grad_enabled() and (x.requires_grad or any(q.requires_grad for q in self.store.params))
+        y, p = _StackFn.apply(self, x, training, return_attn, need, *self.store.params)
         return y.to(x.dtype), p
 
 

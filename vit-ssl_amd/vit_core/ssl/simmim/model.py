@@ -119,8 +119,7 @@ class _SimMIMRuntime:
 
 class _SimMIMFn(Function):
     @staticmethod
-    def forward(ctx, rt, x, training, *params):
-        need = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    def forward(ctx, rt, x, training, need, *params):
         pred, targets, mask = rt.forward(x, training, save=need)
         ctx.rt = rt
         ctx.mark_non_differentiable(targets, mask)
@@ -136,7 +135,7 @@ class _SimMIMFn(Function):
         ops.cast_bf16(dp, dpb)
         rt.backward(dpb)
         grads = [st.gview(n, p.shape).clone() if p.requires_grad else None for n, p in zip(st.names, st.params)]
-        return (None, None, None, *grads)
+        return (None, None, None, None, *grads)
 
 
 class SimMIMViT(nn.Module):
@@ -187,7 +186,8 @@ class SimMIMViT(nn.Module):
     def forward(self, x: torch.Tensor, return_bool_mask=False):
         R.require_gpu(x, "SimMIMViT")
         rt = self.runtime(x.device)
-        pred, targets, mask = _SimMIMFn.apply(rt, x, self.training, *rt.store.params)
+        need = torch.is_grad_enabled() and any(p.requires_grad for p in rt.store.params)
+        pred, targets, mask = _SimMIMFn.apply(rt, x, self.training, need, *rt.store.params)
         if return_bool_mask:
             return pred, targets, mask
         return pred, targets

@@ -92,8 +92,7 @@ class _ViTRuntime:
 
 class _ViTFn(Function):
     @staticmethod
-    def forward(ctx, rt, x, training, return_attn, *params):
-        need = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    def forward(ctx, rt, x, training, return_attn, need, *params):
         logits, probs = rt.forward(x, training, save=need, return_attn=return_attn)
         ctx.rt = rt
         if return_attn:
@@ -108,7 +107,7 @@ class _ViTFn(Function):
         st.gflat.zero_()
         rt.backward(dlogits)
         grads = [st.gview(n, p.shape).clone() if p.requires_grad else None for n, p in zip(st.names, st.params)]
-        return (None, None, None, None, *grads)
+        return (None, None, None, None, None, *grads)
 
 
 class ViT(nn.Module):
@@ -149,7 +148,8 @@ class ViT(nn.Module):
     def forward(self, x: torch.Tensor, return_attn=False):
         R.require_gpu(x, "ViT")
         rt = self.runtime(x.device)
-        logits, probs = _ViTFn.apply(rt, x, self.training, return_attn, *rt.store.params)
+        need = torch.is_grad_enabled() and any(p.requires_grad for p in rt.store.params)
+        logits, probs = _ViTFn.apply(rt, x, self.training, return_attn, need, *rt.store.params)
         if return_attn:
             return logits, probs
         return logits
