@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ViT-B/16 SimMIM pre-training step (224x224, mask 0.6, bf16 MFMA
+GEMMs, batch 256 per GPU, dropout 0.1, AdamW) on N MI355X GPUs, synthetic data.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = zero_grad -> mask draw -> forward -> L1 -> backward -> (RCCL gradient
+all-reduce, overlapped) -> AdamW, i.e. SimMIMViT.train_step.  Rank 0 prints ONE JSON
+line.  `value` is whole-job images/s; `roofline` is the dominant kernel family (the
+bf16 MFMA GEMMs) timed live with HIP events on the launch stream; `cpu_baseline` is the
+CPU oracle timed on this host's cores on a bounded sample (rank 0, N=1 only)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "vit-ssl_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+
+MODELS = {  # standard ViT families
+    "vit_tiny": dict(D=192, L=12, H=3, F=768),
+    "vit_s": dict(D=384, L=12, H=6, F=1536),
+    "vit_b": dict(D=768, L=12, H=12, F=3072),
+    "vit_l": dict(D=1024, L=24, H=16, F=4096),
+}
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md
+
+
+def train_flops_per_image(D, L, H, F, N, Pd, nm):
+    """Algorithmic-FLOP convention of SURVEY.md section 8(d): dense contractions only,
+    train = 3 x (blocks + head) + 2 x patch projection."""
+    blocks = L * (3 * 2 * N * D * D + 2 * N * N * D + 2 * N * N * D + 2 * N * D * D + 4 * N * D * F)
+    head = 2 * nm * D * Pd
+    proj = 2 * N * Pd * D
+    return 3 * (blocks + head) + 2 * proj
+
+
+def cpu_baseline(cfg, img, P, ratio, seconds_budget=25.0):
+    """Reference-equivalent fp32 CPU step (oracle/vit_oracle.py: zero_grad -> forward ->
+    L1 -> backward -> AdamW, eager, dropout 0.1) on a bounded sample."""
+    from oracle import vit_oracle as O
+    from vit_core.ssl.simmim import SimMIMViT
+    torch.manual_seed(42)
+    cores = torch.get_num_threads()
+    Bc = 8
+    model = SimMIMViT(num_blocks=cfg["L"], input_shape=(3, img, img), embed_dim=cfg["D"], patch_size=P,
+                      num_heads=cfg["H"], mlp_dim=cfg["F"], dropout=0.1, mask_ratio=ratio)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    del model
+    x = torch.rand(Bc, 3, img, img)
+    N = (img // P) ** 2
+    opt_state = {}
+    times = []
+    t_start = time.perf_counter()
+    step = 0
+    while True:
+        mask = O.simple_masking(Bc, N, ratio)
+        t0 = time.perf_counter()
+        O.simmim_train_step(sd, opt_state, x, mask, P, cfg["H"], step + 1, 1e-4, 1e-3, p_drop=0.1)
+        dt = time.perf_counter() - t0
+        step += 1
+        if step > 1:          # first step = warm-up
+            times.append(dt)
+        if step >= 2 and (time.perf_counter() - t_start > seconds_budget or len(times) >= 3):
+            break
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(Bc / med, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"same model/inputs shape, batch {Bc}, {len(times)} measured step(s) after 1 warm-up, fp32 eager, dropout 0.1, AdamW"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="vit_b", choices=sorted(MODELS))
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--img", type=int, default=224)
+    ap.add_argument("--patch", type=int, default=16)
+    ap.add_argument("--mask-ratio", type=float, default=0.6)
+    ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+
+    from vit_core.ssl.simmim import SimMIMViT
+    from vitssl_hip import ops
+    from vitssl_hip.engine import GradReducer
+    from vitssl_hip.optim import FusedAdamW
+
+    cfg = MODELS[args.model]
+    torch.manual_seed(42)                                   # identical init on every rank
+    model = SimMIMViT(num_blocks=cfg["L"], input_shape=(3, args.img, args.img), embed_dim=cfg["D"], patch_size=args.patch,
+                      num_heads=cfg["H"], mlp_dim=cfg["F"], dropout=args.dropout, mask_ratio=args.mask_ratio).to(dev).train()
+    store = model.flat_store()
+    reducer = None
+    if world > 1:
+        dist.broadcast(store.flat, 0)
+        store.mark_dirty()
+        reducer = GradReducer(store.gflat)
+    opt = FusedAdamW(store, lr=1e-4, weight_decay=1e-3)
+    gen = torch.Generator().manual_seed(42 + rank)
+    x = torch.rand(args.batch, 3, args.img, args.img, generator=gen).to(dev)
+    torch.manual_seed(1000 + rank)                          # masks / dropout seeds are rank-local
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = model.train_step(x, opt, reducer)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = model.train_step(x, opt, reducer)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt)
+    final_loss = float(loss)
+
+    N = (args.img // args.patch) ** 2
+    Pd = 3 * args.patch * args.patch
+    nm = int(N * args.mask_ratio)
+    fl_img = train_flops_per_image(cfg["D"], cfg["L"], cfg["H"], cfg["F"], N, Pd, nm)
+    ms_per_step = elapsed / args.steps * 1e3
+    imgs_per_s = args.batch * world * args.steps / elapsed
+    step_tflops = fl_img * args.batch / (ms_per_step * 1e-3) / 1e12      # per GPU
+
+    # ---- live kernel timing of one instrumented step (HIP events on the launch stream)
+    roofline = None
+    kernels = {}
+    if not args.no_kernel_timing:
+        ops.PROFILE = []
+        model.train_step(x, opt, reducer)
+        torch.cuda.synchronize()
+        recs, ops.PROFILE = ops.PROFILE, None
+        fam = {}
+        for label, flops, e0, e1 in recs:
+            ms = e0.elapsed_time(e1)
+            k = label.split("[")[0].split(" ")[0]
+            a = fam.setdefault(k, [0.0, 0.0, 0])
+            a[0] += flops
+            a[1] += ms
+            a[2] += 1
+            b = kernels.setdefault(label, [0.0, 0.0, 0])
+            b[0] += flops
+            b[1] += ms
+            b[2] += 1
+        dom = max(fam.items(), key=lambda kv: kv[1][1])
+        name, (fl, ms, cnt) = dom
+        ach = fl / (ms * 1e-3) / 1e12
+        roofline = {"kernel": name + "_kernel", "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": cnt, "avg_launch_ms": round(ms / cnt, 4),
+                    "alg_flops_per_launch": fl / cnt,
+                    "families": {k: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1), "ms_per_step": round(v[1], 3), "launches": v[2]}
+                                 for k, v in fam.items()}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, args.img, args.patch, args.mask_ratio)
+
+    if rank == 0:
+        out = {
+            "metric": "images_per_sec", "value": round(imgs_per_s, 2), "unit": "images/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.model.replace('_', '-').upper().replace('VIT-', 'ViT-')}/{args.patch} SimMIM {args.img}x{args.img} "
+                                   f"mask {args.mask_ratio} dropout {args.dropout} AdamW, batch {args.batch}/GPU",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+            "per_gpu_images_per_sec": round(imgs_per_s / world, 2),
+            "mfma_util": round(step_tflops / PEAK_BF16_TFLOPS, 4),
+            "step_tflops_per_gpu": round(step_tflops, 1),
+            "train_gflop_per_image": round(fl_img / 1e9, 2),
+            "final_loss": round(final_loss, 5),
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        if os.environ.get("BENCH_KERNELS"):
+            out["kernels"] = {k: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1), "ms": round(v[1], 3), "n": v[2]} for k, v in kernels.items()}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

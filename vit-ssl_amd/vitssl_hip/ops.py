@@ -40,6 +40,26 @@ def make_dropout(p=0.0, seed=0, site=0):
 
 NO_DROP = make_dropout()
 
+# Optional live kernel timing (bench.py): when PROFILE is a list, every GEMM launch is
+# bracketed by HIP events ON THE LAUNCH STREAM and (label, flops, start, end) appended.
+PROFILE = None
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record(torch.cuda.current_stream())
+    return ev
+
+
+def _prof_end(ev0, label, flops):
+    if ev0 is None:
+        return
+    ev1 = torch.cuda.Event(enable_timing=True)
+    ev1.record(torch.cuda.current_stream())
+    PROFILE.append((label, flops, ev0, ev1))
+
 
 def dropout_mask(rows, cols, drop, device):
     keep = torch.empty(rows, cols, dtype=torch.uint8, device=device)
@@ -105,7 +125,9 @@ def gemm_nt(A, B, out0, epilogue, bias=None, aux=None, out1=None, colsum=None, d
     g.out1 = _opt(out1, BF16, "out1", (M, N))
     g.colsum = _opt(colsum, F32, "colsum", (N,))
     g.drop = drop
+    ev = _prof_begin()
     call("vitssl_gemm_bf16_nt", C.byref(g), _stream())
+    _prof_end(ev, f"gemm_nt[epi{epilogue}] {M}x{N}x{K}", 2.0 * M * N * K)
 
 
 def gemm_tn(A, B, Cacc):
@@ -114,15 +136,29 @@ def gemm_tn(A, B, Cacc):
     M2, N2 = B.shape
     if M != M2:
         raise L.VitsslError(f"gemm_tn: M mismatch {M} vs {M2}")
+    ev = _prof_begin()
     call("vitssl_gemm_bf16_tn", _chk(A, BF16, "A"), _chk(B, BF16, "B"), _chk(Cacc, F32, "C", (N1, N2)), M, N1, N2, _stream())
+    _prof_end(ev, f"gemm_tn {N1}x{N2}x{M}", 2.0 * M * N1 * N2)
 
 
 def attn_fwd(qkv, out, lse, B, N, H, dh, probs=None):
+    ev = _prof_begin()
+    _attn_fwd(qkv, out, lse, B, N, H, dh, probs)
+    _prof_end(ev, f"attn_fwd B{B} N{N} H{H}", 4.0 * B * H * N * N * dh)
+
+
+def _attn_fwd(qkv, out, lse, B, N, H, dh, probs=None):
     call("vitssl_attn_fwd", _chk(qkv, BF16, "qkv", (B * N, 3 * H * dh)), _chk(out, BF16, "out", (B * N, H * dh)),
          _chk(lse, F32, "lse", (B, H, N)), _opt(probs, F32, "probs", (B, H, N, N)), B, N, H, dh, _stream())
 
 
 def attn_bwd(qkv, out, dout, lse, dqkv, delta_ws, B, N, H, dh):
+    ev = _prof_begin()
+    _attn_bwd(qkv, out, dout, lse, dqkv, delta_ws, B, N, H, dh)
+    _prof_end(ev, f"attn_bwd B{B} N{N} H{H}", 8.0 * B * H * N * N * dh)
+
+
+def _attn_bwd(qkv, out, dout, lse, dqkv, delta_ws, B, N, H, dh):
     call("vitssl_attn_bwd", _chk(qkv, BF16, "qkv", (B * N, 3 * H * dh)), _chk(out, BF16, "out", (B * N, H * dh)),
          _chk(dout, BF16, "dout", (B * N, H * dh)), _chk(lse, F32, "lse", (B, H, N)),
          _chk(dqkv, BF16, "dqkv", (B * N, 3 * H * dh)), _chk(delta_ws, F32, "delta_ws", (B, H, N)), B, N, H, dh, _stream())
