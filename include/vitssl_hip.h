@@ -176,6 +176,29 @@ int vitssl_adamw(float* p, const float* g, float* m, float* v, int64_t n, float 
 /* teacher = m*teacher + (1-m)*student over flat buffers (ssl/dino/model.py:126-139) */
 int vitssl_ema(float* teacher, const float* student, int64_t n, float m, void* stream);
 
+/* ---- DINO head / loss (vit_core/ssl/dino/head.py:19-23, loss.py:13-29, model.py:91-99) ---- */
+/* F.normalize(dim=1, eps=1e-12): zn bf16 [rows,cols] = z / max(||z||, eps); inv_norm [rows] */
+int vitssl_rownorm_fwd(const float* z, void* zn_bf16, float* inv_norm, int64_t rows, int cols, void* stream);
+/* dz bf16 = inv_norm * (dzn - zn <zn, dzn>) */
+int vitssl_rownorm_bwd(const float* dzn, const void* zn_bf16, const float* inv_norm, void* dz_bf16, int64_t rows, int cols,
+                       void* stream);
+/* weight_norm(dim=0): w_f32[k,:] = g[k] v[k,:] / ||v[k,:]||, inv_vnorm[k] = 1/||v[k,:]|| (cast with
+ * vitssl_cast_transpose_bf16 for the GEMM operands) */
+int vitssl_weightnorm_fold(const float* g, const float* v, float* w_f32, float* inv_vnorm, int K, int D, void* stream);
+/* dg[k] += <dW[k,:], vhat_k>; dv[k,:] += g_k/||v_k|| (dW[k,:] - vhat_k <dW[k,:], vhat_k>) */
+int vitssl_weightnorm_bwd(const float* dw, const float* g, const float* v, const float* inv_vnorm, float* dg, float* dv, int K,
+                          int D, void* stream);
+/* DINOLoss: teacher f32 [G,B,K], student f32 [V,B,K], center f32 [K];
+ * loss_sum += -(1/(G B K)) sum_{b,k} (sum_g softmax((t-c)/tt))(sum_v log_softmax(s/ts));
+ * dstudent bf16 [V,B,K] = gscale * dloss/dstudent (or NULL); t_ws f32 [B,K] scratch. */
+int vitssl_dino_loss(const float* teacher, const float* student, const float* center, float* t_ws, float* loss_sum,
+                     void* dstudent_bf16, int G, int V, int B, int K, float teacher_temp, float student_temp, float gscale,
+                     void* stream);
+/* out[cols] = column sums of x f32 [rows, cols] (overwrites) */
+int vitssl_colsum_f32(const float* x, float* out, int64_t rows, int cols, void* stream);
+/* center = m center + (1-m) colsum * inv_rows   (all-reduce colsum first under data parallelism) */
+int vitssl_center_ema(float* center, const float* colsum, int K, float momentum, float inv_rows, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

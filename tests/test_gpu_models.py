@@ -147,3 +147,92 @@ def test_vit_supervised_matches_reference_golden():
     assert max_abs(full, single) < 1e-5
     # plain tensor return when return_attn is False
     assert isinstance(full, torch.Tensor)
+
+
+# ----------------------------------------------------------------------------- DINO
+def _dino_from_golden():
+    from synth import dino_big_weights
+    from vit_core.ssl.dino import DINOViT
+    g = load_golden("dino_tiny")
+    B, gi, li, patch, D, H, F, blocks, K, G, Lv = (int(v) for v in g["cfg"])
+    model = DINOViT(num_blocks=blocks, input_shape=(3, gi, gi), embed_dim=D, patch_size=patch, num_heads=H, mlp_dim=F,
+                    dropout=0.0, output_dim=K, center_momentum=0.9)
+    sd = split_prefix(g, "sd/")
+    for k, a in dino_big_weights(D).items():
+        sd[k] = t(a)
+    model.load_state_dict(sd)
+    return g, model.to(DEV), sd, (B, gi, li, patch, D, H, F, blocks, K, G, Lv)
+
+
+def test_dino_matches_reference_golden():
+    from synth import summarize, BIG_KEYS
+    from vit_core.ssl.dino.loss import DINOLoss
+    g, model, sd, (B, gi, li, patch, D, H, F, blocks, K, G, Lv) = _dino_from_golden()
+    assert not any(p.requires_grad for n, p in model.named_parameters() if n.startswith("teacher_"))
+    views = [(t(g[f"view{i}_u8"]).float() / 256.0).to(DEV) for i in range(G + Lv)]
+    model.train()
+    assert max_abs(model.center, t(g["center0"])) == 0
+    teacher, student = model(views, G)
+    assert teacher.shape == (G * B, K) and student.shape == ((G + Lv) * B, K)
+    assert not teacher.requires_grad
+    assert rel_l2(teacher, t(g["teacher"])) < 2e-2
+    assert rel_l2(student, t(g["student"])) < 2e-2
+    assert rel_l2(model.center, t(g["center1"])) < 2e-2          # centre updated inside forward
+    crit = DINOLoss(teacher_temp=0.04, student_temp=0.1)
+    loss = crit(teacher.view(G, B, K), student.view(G + Lv, B, K), model.center)
+    assert abs(float(loss) - float(g["loss"])) < 1e-2 * abs(float(g["loss"]))
+    # the loss kernel itself, on the reference's exact logits: tight
+    lt, ls, c1 = t(g["teacher"]).to(DEV), t(g["student"]).to(DEV).requires_grad_(True), t(g["center1"]).to(DEV)
+    loss_exact = crit(lt.view(G, B, K), ls.view(G + Lv, B, K), c1)
+    assert abs(float(loss_exact) - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    loss_exact.backward()
+    ls_cpu = t(g["student"]).clone().requires_grad_(True)
+    O.dino_loss_naive(t(g["teacher"]).view(G, B, K), ls_cpu.view(G + Lv, B, K), t(g["center1"]), 0.04, 0.1).backward()
+    assert rel_l2(ls.grad, ls_cpu.grad) < 1e-2                   # bf16-stored gradient
+    loss.backward()
+    ref = split_prefix(g, "grad/")
+    for k, p in model.named_parameters():
+        if k.startswith("teacher_"):
+            assert p.grad is None, k
+            continue
+        assert p.grad is not None, k
+        if any(k.endswith(b) for b in BIG_KEYS) and "_head." in k:
+            s = summarize(p.grad.cpu().numpy())
+            assert rel_l2(t(s["rows"]), t(g[f"gradsum/{k}/rows"])) < 8e-2, k
+            assert rel_l2(t(s["cols"]), t(g[f"gradsum/{k}/cols"])) < 8e-2, k
+        else:
+            assert rel_l2(p.grad, ref[k]) < 8e-2, (k, rel_l2(p.grad, ref[k]))
+    # EMA over the flat stores == per-tensor reference update
+    model.momentum_update_teacher(0.996)
+    for k, want in split_prefix(g, "ema/").items():
+        assert max_abs(dict(model.state_dict())[k], want) < 1e-6, k
+    feats = model.inference_forward(views[0], return_features=True)
+    assert rel_l2(feats, t(g["feats"])) < 2e-2 and not model.training
+    out = model.inference_forward(views[0])
+    assert out.shape == (B, K)
+
+
+def test_dino_fused_step_runs_and_matches_autograd_loss():
+    from vit_core.ssl.dino.loss import DINOLoss
+    from vitssl_hip.optim import FusedAdamW
+    g, model, sd, (B, gi, li, patch, D, H, F, blocks, K, G, Lv) = _dino_from_golden()
+    views = [(t(g[f"view{i}_u8"]).float() / 256.0).to(DEV) for i in range(G + Lv)]
+    model.train()
+    crit = DINOLoss(0.04, 0.1)
+    opt = FusedAdamW(model.trainable_store(), lr=1e-4, weight_decay=1e-3)
+    teacher_before = model.teacher_head.mlp[0].bias.detach().clone()
+    student_before = model.student_head.mlp[0].bias.detach().clone()
+    loss = model.train_step(views, G, crit, opt, None, teacher_momentum=0.9)
+    assert abs(float(loss) - float(g["loss"])) < 1e-2 * abs(float(g["loss"]))
+    st = model.trainable_store()
+    ref = split_prefix(g, "grad/")
+    for k in ("student_backbone.patch_embedding.positional_embedding", "student_head.mlp.4.bias",
+              "student_head.fully_connected.parametrizations.weight.original0",
+              "student_backbone.encoder_blocks.0.self_attention.w_key.weight"):
+        assert rel_l2(st.gview(k), ref[k].reshape(-1)) < 8e-2, k
+    student_after = model.student_head.mlp[0].bias.detach()
+    assert not torch.equal(student_after, student_before)                     # AdamW moved the student
+    want = 0.9 * teacher_before + 0.1 * student_after                        # EMA uses the UPDATED student
+    assert max_abs(model.teacher_head.mlp[0].bias, want) < 1e-6
+    loss2 = model.train_step(views, G, crit, opt, None, teacher_momentum=0.9)
+    assert torch.isfinite(loss2)

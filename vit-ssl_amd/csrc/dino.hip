@@ -1,0 +1,259 @@
+// DINO head / loss kernels (gfx950, HBM-bound): row L2 normalisation, weight-norm fold,
+// softmax / log-softmax cross-entropy over K = 65536 outputs with the algebraic
+// reduction  loss = -(1/(G B K)) sum_{b,k} (sum_g t_g)(sum_v s_v)   (the
+// reference's DINOLoss includes same-view pairs and divides by K), centre update.
+#include "common.h"
+
+namespace {
+
+constexpr int DN_THREADS = 256;
+
+__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
+  v = is_max ? wave_max(v) : wave_sum(v);
+  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[wave] = v;
+  __syncthreads();
+  float r = red[0];
+  for (int w = 1; w < nw; ++w) r = is_max ? fmaxf(r, red[w]) : r + red[w];
+  return r;
+}
+
+// ---- F.normalize(dim=1, eps=1e-12): wave per row ---------------------------------
+__global__ void rownorm_fwd_kernel(const float* __restrict__ z, bf16_t* __restrict__ zn, float* __restrict__ inv_norm,
+                                   long long rows, int cols) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* zr = z + row * cols;
+  float ss = 0.f;
+  for (int c = lane * 4; c < cols; c += 256) {
+    const f32x4 v = *(const f32x4*)(zr + c);
+    ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  ss = wave_sum(ss);
+  const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+  if (lane == 0) inv_norm[row] = inv;
+  for (int c = lane * 4; c < cols; c += 256) {
+    const f32x4 v = *(const f32x4*)(zr + c) * inv;
+    u32x2 w = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+    *(u32x2*)(zn + row * cols + c) = w;
+  }
+}
+
+// dz = inv_norm * (dzn - zn * <zn, dzn>)
+__global__ void rownorm_bwd_kernel(const float* __restrict__ dzn, const bf16_t* __restrict__ zn, const float* __restrict__ inv_norm,
+                                   bf16_t* __restrict__ dz, long long rows, int cols) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float dot = 0.f;
+  for (int c = lane * 4; c < cols; c += 256) {
+    const f32x4 d = *(const f32x4*)(dzn + row * cols + c);
+    const u32x2 w = *(const u32x2*)(zn + row * cols + c);
+    dot += d[0] * bf_lo(w[0]) + d[1] * bf_hi(w[0]) + d[2] * bf_lo(w[1]) + d[3] * bf_hi(w[1]);
+  }
+  dot = wave_sum(dot);
+  const float inv = inv_norm[row];
+  for (int c = lane * 4; c < cols; c += 256) {
+    const f32x4 d = *(const f32x4*)(dzn + row * cols + c);
+    const u32x2 w = *(const u32x2*)(zn + row * cols + c);
+    const f32x4 n = {bf_lo(w[0]), bf_hi(w[0]), bf_lo(w[1]), bf_hi(w[1])};
+    const f32x4 o = (d - n * dot) * inv;
+    u32x2 ow = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+    *(u32x2*)(dz + row * cols + c) = ow;
+  }
+}
+
+// ---- weight_norm(dim=0): W[k,:] = g[k] * v[k,:] / ||v[k,:]||; wave per output row ------
+__global__ void weightnorm_fold_kernel(const float* __restrict__ g, const float* __restrict__ v, float* __restrict__ w,
+                                       float* __restrict__ inv_vnorm, int K, int D) {
+  const int lane = threadIdx.x & 63;
+  const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (k >= K) return;
+  const float* vr = v + (long long)k * D;
+  float ss = 0.f;
+  for (int c = lane * 4; c < D; c += 256) {
+    const f32x4 x = *(const f32x4*)(vr + c);
+    ss += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+  }
+  ss = wave_sum(ss);
+  const float inv = rsqrtf(ss);
+  if (lane == 0) inv_vnorm[k] = inv;
+  const float s = g[k] * inv;
+  for (int c = lane * 4; c < D; c += 256) {
+    *(f32x4*)(w + (long long)k * D + c) = *(const f32x4*)(vr + c) * s;
+  }
+}
+
+// dg[k] += <dW[k,:], vhat> ; dv[k,:] += g*inv*(dW[k,:] - vhat*<dW[k,:], vhat>)
+__global__ void weightnorm_bwd_kernel(const float* __restrict__ dw, const float* __restrict__ g, const float* __restrict__ v,
+                                      const float* __restrict__ inv_vnorm, float* __restrict__ dg, float* __restrict__ dv, int K, int D) {
+  const int lane = threadIdx.x & 63;
+  const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (k >= K) return;
+  const float inv = inv_vnorm[k];
+  float dot = 0.f;
+  for (int c = lane * 4; c < D; c += 256) {
+    const f32x4 d = *(const f32x4*)(dw + (long long)k * D + c);
+    const f32x4 x = *(const f32x4*)(v + (long long)k * D + c);
+    dot += d[0] * x[0] + d[1] * x[1] + d[2] * x[2] + d[3] * x[3];
+  }
+  dot = wave_sum(dot) * inv;   // <dW, vhat>
+  if (lane == 0) dg[k] += dot;
+  const float s = g[k] * inv;
+  for (int c = lane * 4; c < D; c += 256) {
+    const f32x4 d = *(const f32x4*)(dw + (long long)k * D + c);
+    const f32x4 x = *(const f32x4*)(v + (long long)k * D + c) * inv;
+    f32x4 o = *(const f32x4*)(dv + (long long)k * D + c);
+    o += (d - x * dot) * s;
+    *(f32x4*)(dv + (long long)k * D + c) = o;
+  }
+}
+
+// ---- DINO loss -----------------------------------------------------------------------
+// phase 1: T[b,:] = sum_g softmax((teacher[g,b,:] - center) / tau_t); one block per b
+__global__ void dino_teacher_kernel(const float* __restrict__ teacher, const float* __restrict__ center, float* __restrict__ T,
+                                    int G, int B, int K, float inv_tau) {
+  __shared__ float red[DN_THREADS / 64];
+  const int b = blockIdx.x;
+  for (int g = 0; g < G; ++g) {
+    const float* tr = teacher + ((long long)g * B + b) * K;
+    float m = -INFINITY;
+    for (int k = threadIdx.x * 4; k < K; k += DN_THREADS * 4) {
+      const f32x4 x = (*(const f32x4*)(tr + k) - *(const f32x4*)(center + k)) * inv_tau;
+      m = fmaxf(fmaxf(m, fmaxf(x[0], x[1])), fmaxf(x[2], x[3]));
+    }
+    m = block_reduce(m, red, true);
+    float s = 0.f;
+    for (int k = threadIdx.x * 4; k < K; k += DN_THREADS * 4) {
+      const f32x4 x = (*(const f32x4*)(tr + k) - *(const f32x4*)(center + k)) * inv_tau;
+      s += __expf(x[0] - m) + __expf(x[1] - m) + __expf(x[2] - m) + __expf(x[3] - m);
+    }
+    s = block_reduce(s, red, false);
+    const float inv = 1.0f / s;
+    for (int k = threadIdx.x * 4; k < K; k += DN_THREADS * 4) {
+      const f32x4 x = (*(const f32x4*)(tr + k) - *(const f32x4*)(center + k)) * inv_tau;
+      f32x4 p = {__expf(x[0] - m) * inv, __expf(x[1] - m) * inv, __expf(x[2] - m) * inv, __expf(x[3] - m) * inv};
+      if (g > 0) p += *(const f32x4*)(T + (long long)b * K + k);
+      *(f32x4*)(T + (long long)b * K + k) = p;
+    }
+  }
+}
+
+// phase 2: one block per student row (v, b)
+__global__ void dino_student_kernel(const float* __restrict__ student, const float* __restrict__ T, float* __restrict__ loss_sum,
+                                    bf16_t* __restrict__ dstudent, int G, int B, int K, float inv_tau, float gscale) {
+  __shared__ float red[DN_THREADS / 64];
+  const long long row = blockIdx.x;
+  const int b = (int)(row % B);
+  const float* sr = student + row * K;
+  const float* tb = T + (long long)b * K;
+  float m = -INFINITY;
+  for (int k = threadIdx.x * 4; k < K; k += DN_THREADS * 4) {
+    const f32x4 x = *(const f32x4*)(sr + k) * inv_tau;
+    m = fmaxf(fmaxf(m, fmaxf(x[0], x[1])), fmaxf(x[2], x[3]));
+  }
+  m = block_reduce(m, red, true);
+  float s = 0.f;
+  for (int k = threadIdx.x * 4; k < K; k += DN_THREADS * 4) {
+    const f32x4 x = *(const f32x4*)(sr + k) * inv_tau;
+    s += __expf(x[0] - m) + __expf(x[1] - m) + __expf(x[2] - m) + __expf(x[3] - m);
+  }
+  s = block_reduce(s, red, false);
+  const float lse = m + __logf(s);
+  const float norm = 1.0f / ((float)G * (float)B * (float)K);
+  const float gs = gscale * inv_tau * norm;   // d loss / d logit = gs * (G * p - T)
+  float acc = 0.f;
+  for (int k = threadIdx.x * 4; k < K; k += DN_THREADS * 4) {
+    const f32x4 x = *(const f32x4*)(sr + k) * inv_tau - lse;   // log-softmax
+    const f32x4 t = *(const f32x4*)(tb + k);
+    acc += t[0] * x[0] + t[1] * x[1] + t[2] * x[2] + t[3] * x[3];
+    if (dstudent) {
+      float d[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) d[r] = gs * ((float)G * __expf(x[r]) - t[r]);
+      u32x2 w = {pack_bf2(d[0], d[1]), pack_bf2(d[2], d[3])};
+      *(u32x2*)(dstudent + row * K + k) = w;
+    }
+  }
+  acc = block_reduce(acc, red, false);
+  if (threadIdx.x == 0) atomicAdd(loss_sum, -acc * norm);
+}
+
+// ---- centre --------------------------------------------------------------------------
+__global__ void colsum_f32_kernel(const float* __restrict__ x, float* __restrict__ out, long long rows, int cols) {
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (c >= cols) return;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (long long r = 0; r < rows; ++r) acc += *(const f32x4*)(x + r * cols + c);
+  *(f32x4*)(out + c) = acc;
+}
+
+__global__ void center_ema_kernel(float* __restrict__ center, const float* __restrict__ colsum, int K, float mom, float inv_rows) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < K) center[k] = mom * center[k] + (1.f - mom) * colsum[k] * inv_rows;
+}
+
+}  // namespace
+
+extern "C" int vitssl_rownorm_fwd(const float* z, void* zn_bf16, float* inv_norm, int64_t rows, int cols, void* stream) {
+  VS_CHECK_ARG(z && zn_bf16 && inv_norm && rows > 0 && cols > 0 && cols % 4 == 0, "rownorm_fwd: bad args");
+  hipLaunchKernelGGL(rownorm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, z, (bf16_t*)zn_bf16,
+                     inv_norm, (long long)rows, cols);
+  VS_CHECK_LAUNCH("rownorm_fwd");
+  return VITSSL_OK;
+}
+
+extern "C" int vitssl_rownorm_bwd(const float* dzn, const void* zn_bf16, const float* inv_norm, void* dz_bf16, int64_t rows,
+                                  int cols, void* stream) {
+  VS_CHECK_ARG(dzn && zn_bf16 && inv_norm && dz_bf16 && rows > 0 && cols > 0 && cols % 4 == 0, "rownorm_bwd: bad args");
+  hipLaunchKernelGGL(rownorm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dzn,
+                     (const bf16_t*)zn_bf16, inv_norm, (bf16_t*)dz_bf16, (long long)rows, cols);
+  VS_CHECK_LAUNCH("rownorm_bwd");
+  return VITSSL_OK;
+}
+
+extern "C" int vitssl_weightnorm_fold(const float* g, const float* v, float* w_f32, float* inv_vnorm, int K, int D, void* stream) {
+  VS_CHECK_ARG(g && v && w_f32 && inv_vnorm && K > 0 && D > 0 && D % 4 == 0, "weightnorm_fold: bad args");
+  hipLaunchKernelGGL(weightnorm_fold_kernel, dim3((K + 3) / 4), dim3(256), 0, (hipStream_t)stream, g, v, w_f32, inv_vnorm, K, D);
+  VS_CHECK_LAUNCH("weightnorm_fold");
+  return VITSSL_OK;
+}
+
+extern "C" int vitssl_weightnorm_bwd(const float* dw, const float* g, const float* v, const float* inv_vnorm, float* dg, float* dv,
+                                     int K, int D, void* stream) {
+  VS_CHECK_ARG(dw && g && v && inv_vnorm && dg && dv && K > 0 && D > 0 && D % 4 == 0, "weightnorm_bwd: bad args");
+  hipLaunchKernelGGL(weightnorm_bwd_kernel, dim3((K + 3) / 4), dim3(256), 0, (hipStream_t)stream, dw, g, v, inv_vnorm, dg, dv, K, D);
+  VS_CHECK_LAUNCH("weightnorm_bwd");
+  return VITSSL_OK;
+}
+
+extern "C" int vitssl_dino_loss(const float* teacher, const float* student, const float* center, float* t_ws, float* loss_sum,
+                                void* dstudent_bf16, int G, int V, int B, int K, float teacher_temp, float student_temp,
+                                float gscale, void* stream) {
+  VS_CHECK_ARG(teacher && student && center && t_ws && loss_sum, "dino_loss: null pointer");
+  VS_CHECK_ARG(G > 0 && V > 0 && B > 0 && K > 0 && K % 4 == 0, "dino_loss: K=%d must be a positive multiple of 4", K);
+  VS_CHECK_ARG(teacher_temp > 0.f && student_temp > 0.f, "dino_loss: temperatures must be positive");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(dino_teacher_kernel, dim3(B), dim3(DN_THREADS), 0, s, teacher, center, t_ws, G, B, K, 1.0f / teacher_temp);
+  VS_CHECK_LAUNCH("dino_teacher");
+  hipLaunchKernelGGL(dino_student_kernel, dim3(V * B), dim3(DN_THREADS), 0, s, student, t_ws, loss_sum, (bf16_t*)dstudent_bf16, G, B,
+                     K, 1.0f / student_temp, gscale);
+  VS_CHECK_LAUNCH("dino_student");
+  return VITSSL_OK;
+}
+
+extern "C" int vitssl_colsum_f32(const float* x, float* out, int64_t rows, int cols, void* stream) {
+  VS_CHECK_ARG(x && out && rows > 0 && cols > 0 && cols % 4 == 0, "colsum_f32: bad args");
+  hipLaunchKernelGGL(colsum_f32_kernel, dim3((cols / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, out, (long long)rows, cols);
+  VS_CHECK_LAUNCH("colsum_f32");
+  return VITSSL_OK;
+}
+
+extern "C" int vitssl_center_ema(float* center, const float* colsum, int K, float momentum, float inv_rows, void* stream) {
+  VS_CHECK_ARG(center && colsum && K > 0, "center_ema: bad args");
+  hipLaunchKernelGGL(center_ema_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, center, colsum, K, momentum, inv_rows);
+  VS_CHECK_LAUNCH("center_ema");
+  return VITSSL_OK;
+}

@@ -1,0 +1,70 @@
+"""DINO trainer (reference: utils/trainers/dino_trainer.py:14-173): per-EPOCH cosine
+schedules for the teacher temperature and the EMA momentum, multi-crop step, teacher
+momentum update after the optimizer step.  Views arrive as a list of V tensors (G global
+first).  AdamW => the fused engine step; otherwise the reference-style autograd path."""
+import logging
+
+import torch
+
+from vit_core.ssl.dino.dino_utils import DINOMomentumScheduler, DINOTeacherTempScheduler
+from vit_core.ssl.dino.loss import DINOLoss
+
+from .._config import cfg_get
+from .base_trainer import BaseTrainer
+
+logger = logging.getLogger(__name__)
+
+
+class DINOTrainer(BaseTrainer):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        t = lambda k, d=None: cfg_get(self.config, "training", k, default=d)  # noqa: E731
+        self.num_global_views = cfg_get(self.config, "data", "num_global_views", default=t("num_global_views", 2))
+        self.temp_sched = DINOTeacherTempScheduler(t("teacher_temp_start", 0.04), t("teacher_temp_final", 0.07),
+                                                   t("teacher_temp_warmup_epochs", 30))
+        self.mom_sched = DINOMomentumScheduler(t("teacher_momentum_start", 0.996), t("teacher_momentum_final", 1.0), self.num_epochs)
+
+    def create_criterion(self):
+        t = lambda k, d=None: cfg_get(self.config, "training", k, default=d)  # noqa: E731
+        return DINOLoss(teacher_temp=t("teacher_temp_start", 0.04), student_temp=t("student_temp", 0.1))
+
+    def _loss(self, views):
+        G = self.num_global_views
+        teacher, student = self.model(views, G)
+        B = views[0].shape[0]
+        K = teacher.shape[-1]
+        return self.criterion(teacher.view(G, B, K), student.view(len(views), B, K), self.model.center)
+
+    def train_epoch(self, epoch: int):
+        self.model.train()
+        self.criterion.teacher_temp = self.temp_sched.get_temp(epoch - 1)
+        momentum = self.mom_sched.get_momentum(epoch - 1)
+        fused = self._is_fused()
+        total, running = 0, None
+        for idx, inputs in enumerate(self.train_loader):
+            views = [v.to(self.device, non_blocking=True) for v in inputs]
+            if fused:
+                loss = self.model.train_step(views, self.num_global_views, self.criterion, self.optimizer, self.reducer, momentum)
+            else:
+                self.optimizer.zero_grad(set_to_none=True)
+                loss = self._loss(views)
+                loss.backward()
+                self._generic_reduce()
+                self.optimizer.step()
+                self.model.momentum_update_teacher(momentum)
+                loss = loss.detach()
+            self._warmup_step(epoch)
+            running = loss if running is None else running + loss
+            total += 1
+        return {"Loss": float(running) / max(total, 1), "TeacherTemp": self.criterion.teacher_temp, "Momentum": momentum}
+
+    def validate(self):
+        self.model.eval()
+        total, running = 0, None
+        with torch.no_grad():
+            for idx, inputs in enumerate(self.val_loader):
+                views = [v.to(self.device, non_blocking=True) for v in inputs]
+                loss = self._loss(views)
+                running = loss if running is None else running + loss
+                total += 1
+        return {"Loss": float(running) / max(total, 1) if total else float("nan")}

@@ -57,6 +57,13 @@ PROTOTYPES = {
     "vitssl_cast_transpose_bf16": [_vp, _vp, _vp, _i, _i, _vp],
     "vitssl_adamw": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _vp],
     "vitssl_ema": [_vp, _vp, _i64, _f, _vp],
+    "vitssl_rownorm_fwd": [_vp, _vp, _vp, _i64, _i, _vp],
+    "vitssl_rownorm_bwd": [_vp, _vp, _vp, _vp, _i64, _i, _vp],
+    "vitssl_weightnorm_fold": [_vp, _vp, _vp, _vp, _i, _i, _vp],
+    "vitssl_weightnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "vitssl_dino_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp],
+    "vitssl_colsum_f32": [_vp, _vp, _i64, _i, _vp],
+    "vitssl_center_ema": [_vp, _vp, _i, _f, _f, _vp],
 }
 
 _lib = None

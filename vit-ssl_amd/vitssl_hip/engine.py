@@ -84,6 +84,7 @@ class FlatStore:
         self._bf16: Dict[str, torch.Tensor] = {}
         self._bf16_version = -1
         self._dirty = True
+        self.generation = 0   # bumped whenever the flat buffer is rewritten behind torch's back
         self._cast_jobs: List[Tuple[str, Callable[[], torch.Tensor], bool]] = []
 
     # ---- bookkeeping -------------------------------------------------------
@@ -127,6 +128,10 @@ class FlatStore:
 
     def mark_dirty(self):
         self._dirty = True
+        self.generation += 1
+
+    def weights_key(self):
+        return (self.generation, self.flat._version)
 
     # ---- bf16 weight caches --------------------------------------------------
     def register_weight(self, key: str, src: Callable[[], torch.Tensor], transposed_too: bool = True):

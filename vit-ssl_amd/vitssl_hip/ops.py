@@ -239,3 +239,43 @@ def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step, gscale=1.0):
 
 def ema(teacher, student, m):
     call("vitssl_ema", _chk(teacher, F32, "teacher"), _chk(student, F32, "student", teacher.shape), teacher.numel(), float(m), _stream())
+
+
+# ---- DINO ----------------------------------------------------------------------------
+def rownorm_fwd(z, zn, inv_norm):
+    rows, cols = z.shape
+    call("vitssl_rownorm_fwd", _chk(z, F32, "z"), _chk(zn, BF16, "zn", (rows, cols)), _chk(inv_norm, F32, "inv_norm", (rows,)), rows, cols, _stream())
+
+
+def rownorm_bwd(dzn, zn, inv_norm, dz):
+    rows, cols = dzn.shape
+    call("vitssl_rownorm_bwd", _chk(dzn, F32, "dzn"), _chk(zn, BF16, "zn", (rows, cols)), _chk(inv_norm, F32, "inv_norm", (rows,)),
+         _chk(dz, BF16, "dz", (rows, cols)), rows, cols, _stream())
+
+
+def weightnorm_fold(g, v, w_f32, inv_vnorm):
+    K, D = v.shape
+    call("vitssl_weightnorm_fold", _chk(g, F32, "g"), _chk(v, F32, "v"), _chk(w_f32, F32, "w", (K, D)), _chk(inv_vnorm, F32, "inv_vnorm", (K,)),
+         K, D, _stream())
+
+
+def weightnorm_bwd(dw, g, v, inv_vnorm, dg, dv):
+    K, D = v.shape
+    call("vitssl_weightnorm_bwd", _chk(dw, F32, "dw", (K, D)), _chk(g, F32, "g"), _chk(v, F32, "v"), _chk(inv_vnorm, F32, "inv_vnorm", (K,)),
+         _chk(dg, F32, "dg"), _chk(dv, F32, "dv", (K, D)), K, D, _stream())
+
+
+def dino_loss(teacher, student, center, t_ws, loss_sum, dstudent, G, V, B, K, teacher_temp, student_temp, gscale=1.0):
+    call("vitssl_dino_loss", _chk(teacher, F32, "teacher", (G * B, K)), _chk(student, F32, "student", (V * B, K)),
+         _chk(center, F32, "center"), _chk(t_ws, F32, "t_ws", (B, K)), _chk(loss_sum, F32, "loss_sum", (1,)),
+         _opt(dstudent, BF16, "dstudent", (V * B, K)), G, V, B, K, float(teacher_temp), float(student_temp), float(gscale), _stream())
+
+
+def colsum_f32(x, out):
+    rows, cols = x.shape
+    call("vitssl_colsum_f32", _chk(x, F32, "x"), _chk(out, F32, "out", (cols,)), rows, cols, _stream())
+
+
+def center_ema(center, colsum, momentum, inv_rows):
+    K = colsum.numel()
+    call("vitssl_center_ema", _chk(center, F32, "center"), _chk(colsum, F32, "colsum"), K, float(momentum), float(inv_rows), _stream())
