@@ -116,9 +116,13 @@ typedef struct {
 int vitssl_gemm_bf16_nt(const vitssl_gemm_t* g, void* stream);
 
 /* Weight gradient: C[N1,N2] (fp32) += A[M,N1]^T . B[M,N2]  (contraction over rows).
- * Split over M across workgroups, combined with fp32 atomics: caller zeroes C.
- * N1 % 8 == 0, N2 % 8 == 0. */
-int vitssl_gemm_bf16_tn(const void* A, const void* B, float* C, int64_t M, int N1, int N2, void* stream);
+ * Split over M across workgroups.  With a workspace of at least
+ * vitssl_gemm_tn_workspace_floats(M,N1,N2) floats the partial tiles are combined through
+ * per-split slabs (deterministic, plain stores + one reduce kernel); with workspace=NULL
+ * they are combined with fp32 atomics.  N1 % 8 == 0, N2 % 8 == 0. */
+int64_t vitssl_gemm_tn_workspace_floats(int64_t M, int N1, int N2);
+int vitssl_gemm_bf16_tn(const void* A, const void* B, float* C, int64_t M, int N1, int N2, float* workspace,
+                        int64_t workspace_floats, void* stream);
 
 /* ---- fused multi-head self-attention (vit_core/attention.py:20-23,86-103) ----------
  * qkv  bf16 [B, N, 3, H, dh]  (the fused projection output: q | k | v per token)

@@ -75,10 +75,43 @@ __device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 
 // ------------------------------------------------------------------ forward
-// grid = B*H, 256 threads.  NS = number of 32-key steps (Np = 32*NS >= N).
+// in-register row softmax of one 16-query tile: s holds S^T[key = 16kt + 4g + r][q = lane&15]
+template <int NKT>
+__device__ __forceinline__ void softmax_tile(f32x4 (&s)[NKT], int N, int g, float scale, float& m_out, float& sum_out) {
+  float m = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = kt * 16 + 4 * g + r;
+      s[kt][r] = key < N ? s[kt][r] * scale : -INFINITY;
+      m = fmaxf(m, s[kt][r]);
+    }
+  m = fmaxf(m, __shfl_xor(m, 16, 64));
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s[kt][r] = __expf(s[kt][r] - m);
+      sum += s[kt][r];
+    }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) s[kt] *= inv;
+  m_out = m;
+  sum_out = sum;
+}
+
+// grid = B*H, 256 threads (2 workgroups per CU).  NS = number of 32-key steps
+// (Np = 32*NS >= N).  Each wave processes PAIRS of 16-query tiles so that every K / V
+// fragment read from LDS feeds two MFMAs.
 template <int NS>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                       float* __restrict__ lse, float* __restrict__ probs, int N, int H) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                          float* __restrict__ lse, float* __restrict__ probs, int N, int H) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int Np = 32 * NS;
   constexpr int NKT = 2 * NS;
@@ -97,74 +130,76 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, li = lane & 15;
   const float scale = 0.125f;  // 1/sqrt(64)
-  const int nqt = (N + 15) >> 4;
+  const int nqp = (N + 31) >> 5;   // pairs of 16-query tiles
 
-  for (int qt = wave; qt < nqt; qt += 4) {
-    const int q = qt * 16 + li;
-    const bf16x8 q0 = glb_frag(qg, stride, q, 0, N, lane);
-    const bf16x8 q1 = glb_frag(qg, stride, q, 1, N, lane);
-    f32x4 s[NKT];
+  for (int qp = wave; qp < nqp; qp += 4) {
+    const int q[2] = {qp * 32 + li, qp * 32 + 16 + li};
+    bf16x8 qf[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      qf[t][0] = glb_frag(qg, stride, q[t], 0, N, lane);
+      qf[t][1] = glb_frag(qg, stride, q[t], 1, N, lane);
+    }
+    f32x4 s0[NKT], s1[NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-      f32x4 a = {0.f, 0.f, 0.f, 0.f};
-      a = MFMA16(lds_frag(Kt, kt * 16 + li, 0, lane), q0, a);
-      a = MFMA16(lds_frag(Kt, kt * 16 + li, 1, lane), q1, a);
-      s[kt] = a;
+      const bf16x8 k0 = lds_frag(Kt, kt * 16 + li, 0, lane);
+      const bf16x8 k1 = lds_frag(Kt, kt * 16 + li, 1, lane);
+      f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
+      a = MFMA16(k0, qf[0][0], a);
+      c = MFMA16(k0, qf[1][0], c);
+      a = MFMA16(k1, qf[0][1], a);
+      c = MFMA16(k1, qf[1][1], c);
+      s0[kt] = a;
+      s1[kt] = c;
     }
-    // row softmax over keys: registers, then the 4 lane groups (xor 16, 32)
-    float m = -INFINITY;
+    float m[2], sum[2];
+    softmax_tile<NKT>(s0, N, g, scale, m[0], sum[0]);
+    softmax_tile<NKT>(s1, N, g, scale, m[1], sum[1]);
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
+    for (int t = 0; t < 2; ++t) {
+      if (q[t] < N) {
+        if (g == 0) lse[((long long)b * H + h) * N + q[t]] = m[t] + __logf(sum[t]);
+        if (probs) {
+          float* pr = probs + (((long long)b * H + h) * N + q[t]) * N;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kt * 16 + 4 * g + r;
-        s[kt][r] = key < N ? s[kt][r] * scale : -INFINITY;
-        m = fmaxf(m, s[kt][r]);
-      }
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float sum = 0.f;
+          for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        s[kt][r] = __expf(s[kt][r] - m);
-        sum += s[kt][r];
-      }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) s[kt] *= inv;
-    if (q < N) {
-      if (g == 0) lse[((long long)b * H + h) * N + q] = m + __logf(sum);
-      if (probs) {
-        float* pr = probs + (((long long)b * H + h) * N + q) * N;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int key = kt * 16 + 4 * g + r;
-            if (key < N) pr[key] = s[kt][r];
-          }
+            for (int r = 0; r < 4; ++r) {
+              const int key = kt * 16 + 4 * g + r;
+              if (key < N) pr[key] = t == 0 ? s0[kt][r] : s1[kt][r];
+            }
+        }
       }
     }
     // O^T[d][q] = sum_key V[key][d] P[q][key]
-    f32x4 o[4];
+    f32x4 o0[4], o1[4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < 4; ++dt) {
+      o0[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      o1[dt] = o0[dt];
+    }
 #pragma unroll
     for (int st = 0; st < NS; ++st) {
-      const bf16x8 pf = pack_frag(s[2 * st], s[2 * st + 1]);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) o[dt] = MFMA16(tr_frag(Vt, st, dt, lane), pf, o[dt]);
-    }
-    if (q < N) {
-      bf16_t* og = out + ((long long)b * N + q) * (H * DH) + h * DH;
+      const bf16x8 p0 = pack_frag(s0[2 * st], s0[2 * st + 1]);
+      const bf16x8 p1 = pack_frag(s1[2 * st], s1[2 * st + 1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        u32x2 w = {pack_bf2(o[dt][0], o[dt][1]), pack_bf2(o[dt][2], o[dt][3])};
-        *(u32x2*)(og + dt * 16 + 4 * g) = w;
+        const bf16x8 vf = tr_frag(Vt, st, dt, lane);
+        o0[dt] = MFMA16(vf, p0, o0[dt]);
+        o1[dt] = MFMA16(vf, p1, o1[dt]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (q[t] < N) {
+        bf16_t* og = out + ((long long)b * N + q[t]) * (H * DH) + h * DH;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const f32x4 o = t == 0 ? o0[dt] : o1[dt];
+          u32x2 w = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+          *(u32x2*)(og + dt * 16 + 4 * g) = w;
+        }
       }
     }
   }
@@ -296,11 +331,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16_t* __restr
 }
 
 // ------------------------------------------------------------------ backward: dQ
-// grid = B*H, 256 threads: waves own 16-query tiles; K and V tiles in LDS.
+// grid = B*H, 256 threads (2 workgroups per CU): waves own PAIRS of 16-query tiles;
+// K and V tiles in LDS, each fragment read feeds both tiles.
 template <int NS>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
-                                                          const float* __restrict__ lse, const float* __restrict__ delta,
-                                                          bf16_t* __restrict__ dqkv, int N, int H) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                             const float* __restrict__ lse, const float* __restrict__ delta,
+                                                             bf16_t* __restrict__ dqkv, int N, int H) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int Np = 32 * NS;
   constexpr int NKT = 2 * NS;
@@ -320,44 +356,72 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, li = lane & 15;
   const float scale = 0.125f;
-  const int nqt = (N + 15) >> 4;
+  const int nqp = (N + 31) >> 5;
 
-  for (int qt = wave; qt < nqt; qt += 4) {
-    const int q = qt * 16 + li;
-    const bf16x8 q0 = glb_frag(qg, stride, q, 0, N, lane), q1 = glb_frag(qg, stride, q, 1, N, lane);
-    const bf16x8 d0 = glb_frag(dog, (long long)H * DH, q, 0, N, lane), d1 = glb_frag(dog, (long long)H * DH, q, 1, N, lane);
-    const float l = q < N ? lse[((long long)b * H + h) * N + q] : INFINITY;
-    const float dl = q < N ? delta[((long long)b * H + h) * N + q] : 0.f;
-    f32x4 ds[NKT];
+  for (int qp = wave; qp < nqp; qp += 4) {
+    const int q[2] = {qp * 32 + li, qp * 32 + 16 + li};
+    bf16x8 qf[2][2], df[2][2];
+    float l[2], dl[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      qf[t][0] = glb_frag(qg, stride, q[t], 0, N, lane);
+      qf[t][1] = glb_frag(qg, stride, q[t], 1, N, lane);
+      df[t][0] = glb_frag(dog, (long long)H * DH, q[t], 0, N, lane);
+      df[t][1] = glb_frag(dog, (long long)H * DH, q[t], 1, N, lane);
+      l[t] = q[t] < N ? lse[((long long)b * H + h) * N + q[t]] : INFINITY;
+      dl[t] = q[t] < N ? delta[((long long)b * H + h) * N + q[t]] : 0.f;
+    }
+    f32x4 ds0[NKT], ds1[NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-      f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
-      a = MFMA16(lds_frag(Kt, kt * 16 + li, 0, lane), q0, a);
-      a = MFMA16(lds_frag(Kt, kt * 16 + li, 1, lane), q1, a);
-      c = MFMA16(lds_frag(Vt, kt * 16 + li, 0, lane), d0, c);
-      c = MFMA16(lds_frag(Vt, kt * 16 + li, 1, lane), d1, c);
+      const bf16x8 k0 = lds_frag(Kt, kt * 16 + li, 0, lane), k1 = lds_frag(Kt, kt * 16 + li, 1, lane);
+      const bf16x8 v0 = lds_frag(Vt, kt * 16 + li, 0, lane), v1 = lds_frag(Vt, kt * 16 + li, 1, lane);
+      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, c0 = a0, a1 = a0, c1 = a0;
+      a0 = MFMA16(k0, qf[0][0], a0);
+      a1 = MFMA16(k0, qf[1][0], a1);
+      c0 = MFMA16(v0, df[0][0], c0);
+      c1 = MFMA16(v0, df[1][0], c1);
+      a0 = MFMA16(k1, qf[0][1], a0);
+      a1 = MFMA16(k1, qf[1][1], a1);
+      c0 = MFMA16(v1, df[0][1], c0);
+      c1 = MFMA16(v1, df[1][1], c1);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int key = kt * 16 + 4 * g + r;
-        const float pv = key < N ? __expf(a[r] * scale - l) : 0.f;
-        ds[kt][r] = pv * (c[r] - dl) * scale;
+        const bool valid = kt * 16 + 4 * g + r < N;
+        const float p0 = valid ? __expf(a0[r] * scale - l[0]) : 0.f;
+        const float p1 = valid ? __expf(a1[r] * scale - l[1]) : 0.f;
+        ds0[kt][r] = p0 * (c0[r] - dl[0]) * scale;
+        ds1[kt][r] = p1 * (c1[r] - dl[1]) * scale;
       }
+      __builtin_amdgcn_sched_barrier(0);   // keep fragment live ranges per key tile (256-VGPR budget)
     }
-    f32x4 dq[4];
+    f32x4 dq0[4], dq1[4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < 4; ++dt) {
+      dq0[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dq1[dt] = dq0[dt];
+    }
 #pragma unroll
     for (int st = 0; st < NS; ++st) {
-      const bf16x8 sf = pack_frag(ds[2 * st], ds[2 * st + 1]);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) dq[dt] = MFMA16(tr_frag(Kt, st, dt, lane), sf, dq[dt]);
-    }
-    if (q < N) {
-      bf16_t* dqg = dqkv + ((long long)b * N + q) * stride + h * DH;
+      const bf16x8 f0 = pack_frag(ds0[2 * st], ds0[2 * st + 1]);
+      const bf16x8 f1 = pack_frag(ds1[2 * st], ds1[2 * st + 1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        u32x2 w = {pack_bf2(dq[dt][0], dq[dt][1]), pack_bf2(dq[dt][2], dq[dt][3])};
-        *(u32x2*)(dqg + dt * 16 + 4 * g) = w;
+        const bf16x8 kf = tr_frag(Kt, st, dt, lane);
+        dq0[dt] = MFMA16(kf, f0, dq0[dt]);
+        dq1[dt] = MFMA16(kf, f1, dq1[dt]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (q[t] < N) {
+        bf16_t* dqg = dqkv + ((long long)b * N + q[t]) * stride + h * DH;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const f32x4 o = t == 0 ? dq0[dt] : dq1[dt];
+          u32x2 w = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+          *(u32x2*)(dqg + dt * 16 + 4 * g) = w;
+        }
       }
     }
   }

@@ -17,14 +17,31 @@
 //
 // Pipeline: 2 LDS buffers; the stage of k-tile t+1 is issued before the MFMAs of
 // k-tile t and retired (vmcnt(0) + barrier) after them.
+//
+// Two tile configurations share this code (every wave always owns 128x64 outputs):
+//   BIG   256x256x64, 8 waves, 128 KiB LDS, one workgroup per CU: best main loop;
+//   SMALL 256x128x32, 4 waves,  48 KiB LDS, up to three workgroups per CU: the VALU- and
+//         HBM-heavy epilogue of one workgroup (GELU / dGELU / residual) overlaps the
+//         MFMAs of its neighbours, and the finer tiles fill the 256 CUs better when the
+//         256x256 grid is a poor multiple of 256 (e.g. N = 768: 588 tiles).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
 
-constexpr int BM = 256, BN = 256, BK = 64;
-constexpr int NT_THREADS = 512;
-constexpr int TILE_BYTES = 256 * BK * 2;          // one operand tile
-constexpr int NT_LDS_BYTES = 4 * TILE_BYTES;      // 2 buffers x (A, B) = 128 KiB
+template <int BK_, int WM_, int WN_>
+struct NtCfg {
+  static constexpr int BK = BK_, WM = WM_, WN = WN_;
+  static constexpr int BM = 128 * WM_, BN = 64 * WN_;
+  static constexpr int WAVES = WM_ * WN_, THREADS = 64 * WM_ * WN_;
+  static constexpr int ROWB = BK_ * 2;                       // bytes per tile row
+  static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
+  static constexpr int BUF_BYTES = A_BYTES + B_BYTES;
+  static constexpr int LDS_BYTES = 2 * BUF_BYTES;
+  static constexpr int MIN_WAVES_PER_SIMD = (BK_ == 64) ? 2 : 2;
+};
+using NtBig = NtCfg<64, 2, 4>;
+using NtSmall = NtCfg<32, 2, 2>;
 
 struct NtParams {
   const bf16_t* A;
@@ -40,25 +57,41 @@ struct NtParams {
   int drop_on;
   vitssl_embed_t embed;
   int tiles_m, tiles_n;
+  int group_n;   // tile columns per raster group (their B panels stay L2-resident)
+  int stagger;   // start-up delay units (x ~2.7 us) per phase group, 0 = off
 };
 
+// XOR applied to the 16-byte chunk index of tile row r (source side for the DMA, and on
+// the fragment reads): BK=64 (128-B rows) chunk ^ ((r>>1)&7); BK=32 (64-B rows)
+// chunk ^ 3*((r>>3)&1).  Both make every 16-lane ds_read_b128 group conflict-free.
+template <int BK_>
+__device__ __forceinline__ int nt_swz(int r) {
+  return BK_ == 64 ? ((r >> 1) & 7) : 3 * ((r >> 3) & 1);
+}
+
+template <int BK_, int ROWS, int WAVES>
 __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, long long row0, int k0,
                                            int K, int wave, int lane) {
-  // 32 wave-instructions cover the 256-row tile; this wave issues 4 of them.
+  constexpr int ROWB = BK_ * 2;
+  constexpr int RPI = 1024 / ROWB;              // tile rows per 1-KiB wave-instruction
+  constexpr int LPR = ROWB / 16;                // lanes per row
+  constexpr int SLOTS = ROWS / RPI;
+  static_assert(SLOTS % WAVES == 0, "tile rows must split evenly over the waves");
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int i = wave * 4 + j;                 // wave-uniform instruction slot
-    const int r = i * 8 + (lane >> 3);          // tile row this lane fetches for
-    const int c = lane & 7;                     // 16-B chunk position in the LDS row
-    const int sc = c ^ ((r >> 1) & 7);          // chunk fetched from global
+  for (int j = 0; j < SLOTS / WAVES; ++j) {
+    const int i = wave * (SLOTS / WAVES) + j;   // wave-uniform instruction slot
+    const int r = i * RPI + lane / LPR;         // tile row this lane fetches for
+    const int c = lane % LPR;                   // 16-B chunk position in the LDS row
+    const int sc = c ^ nt_swz<BK_>(r);          // chunk fetched from global
     const unsigned voff = (unsigned)(((row0 + r) * (long long)K + k0) * 2 + sc * 16);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + i * 1024), 16, voff, 0, 0, 0);
   }
 }
 
-template <int EPI>
-__global__ __launch_bounds__(NT_THREADS) void gemm_nt_kernel(NtParams p) {
+template <int EPI, typename CFG>
+__global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt_kernel(NtParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK;
 
   // XCD-aware bijective remap: blocks b, b+8, ... share an XCD (round-robin dispatch);
   // give each XCD a contiguous run of tiles so neighbouring tiles (same A row-panel,
@@ -67,14 +100,29 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_nt_kernel(NtParams p) {
   const int bid = blockIdx.x;
   const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
   const int wgid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
-  const int tile_m = wgid / p.tiles_n;
-  const int tile_n = wgid - tile_m * p.tiles_n;
+  // column-group-major order: all tile rows of a group of `group_n` tile columns, then
+  // the next group -> a group's weight panels are re-used from L2 by every tile row.
+  const int full = p.tiles_m * p.group_n;
+  const int cg = wgid / full;
+  const int rem = wgid - cg * full;
+  const int gw = min(p.group_n, p.tiles_n - cg * p.group_n);
+  const int tile_m = rem / gw;
+  const int tile_n = cg * p.group_n + (rem - tile_m * gw);
   const long long m0 = (long long)tile_m * BM;
   const int n0 = tile_n * BN;
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = wave / CFG::WN, wn = wave % CFG::WN;
+
+  // Phase stagger: every tile costs the same, so the 256 CUs would run their
+  // HBM-heavy epilogues in lock-step (a chip-wide burst, then an idle HBM during the
+  // main loops).  Delaying the first wave of workgroups by 0..3 quarter tile periods
+  // spreads the epilogues of different CUs over the others' main loops.
+  if (p.stagger > 0 && bid < 256) {
+    const int grp = (bid >> 3) & 3;
+    for (int i = 0; i < grp * p.stagger; ++i) __builtin_amdgcn_s_sleep(100);
+  }
 
   const unsigned long long a_bytes = (unsigned long long)p.M * p.K * 2ull;
   const unsigned long long b_bytes = (unsigned long long)p.N * p.K * 2ull;
@@ -88,33 +136,33 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_nt_kernel(NtParams p) {
     for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / BK;
-  stage_tile(rsA, smem, m0, 0, p.K, wave, lane);
-  stage_tile(rsB, smem + TILE_BYTES, n0, 0, p.K, wave, lane);
+  stage_tile<BK, BM, CFG::WAVES>(rsA, smem, m0, 0, p.K, wave, lane);
+  stage_tile<BK, BN, CFG::WAVES>(rsB, smem + CFG::A_BYTES, n0, 0, p.K, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  const int swz = (lane >> 1) & 7;                 // (row>>1)&7 with row = 16*x + (lane&15)
+  const int swz = nt_swz<BK>(lane & 15);           // rows are 16*x + (lane&15)
   const int frag_row = lane & 15;
   const int kq = lane >> 4;
 
   for (int t = 0; t < nk; ++t) {
-    char* bufA = smem + (t & 1) * 2 * TILE_BYTES;
-    char* bufB = bufA + TILE_BYTES;
+    char* bufA = smem + (t & 1) * CFG::BUF_BYTES;
+    char* bufB = bufA + CFG::A_BYTES;
     if (t + 1 < nk) {
-      char* nA = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
-      stage_tile(rsA, nA, m0, (t + 1) * BK, p.K, wave, lane);
-      stage_tile(rsB, nA + TILE_BYTES, n0, (t + 1) * BK, p.K, wave, lane);
+      char* nA = smem + ((t + 1) & 1) * CFG::BUF_BYTES;
+      stage_tile<BK, BM, CFG::WAVES>(rsA, nA, m0, (t + 1) * BK, p.K, wave, lane);
+      stage_tile<BK, BN, CFG::WAVES>(rsB, nA + CFG::A_BYTES, n0, (t + 1) * BK, p.K, wave, lane);
     }
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int kk = 0; kk < BK / 32; ++kk) {
       const int coff = ((kk * 4 + kq) ^ swz) << 4;
       bf16x8 fb[4], fa[8];
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        fb[j] = *(const bf16x8*)(bufB + (wn * 64 + j * 16 + frag_row) * 128 + coff);
+        fb[j] = *(const bf16x8*)(bufB + (wn * 64 + j * 16 + frag_row) * CFG::ROWB + coff);
 #pragma unroll
       for (int i = 0; i < 8; ++i)
-        fa[i] = *(const bf16x8*)(bufA + (wm * 128 + i * 16 + frag_row) * 128 + coff);
+        fa[i] = *(const bf16x8*)(bufA + (wm * 128 + i * 16 + frag_row) * CFG::ROWB + coff);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -133,65 +181,111 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_nt_kernel(NtParams p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) csum[j][r] = 0.f;
   }
+  const int g4 = lane >> 4;                       // lane group = 16-lane row of the wave
+  // bf16 outputs: tile columns (j, j+1) exchange halves between lane rows (g, g^1) with
+  // v_permlane16_swap so that every lane stores 16 contiguous bytes (8 columns).
+  const bool wide = (p.N & 7) == 0;
+
+  auto store_bf16_pair = [&](bf16_t* base, long long m, int jp, const u32x2& w0, const u32x2& w1, bool ok0, bool ok1, bool okm) {
+    if (wide) {
+      // after the swap: even rows hold tile 2jp  cols 4g .. 4g+7, odd rows tile 2jp+1 cols 4(g-1) .. 4(g-1)+7
+      auto lo = __builtin_amdgcn_permlane16_swap(w0[0], w1[0], false, false);
+      auto hi = __builtin_amdgcn_permlane16_swap(w0[1], w1[1], false, false);
+      const int odd = g4 & 1;
+      const int n = n0 + wn * 64 + (2 * jp + odd) * 16 + 4 * (g4 - odd);
+      if (okm && n < p.N) {
+        u32x4 v = {lo[0], hi[0], lo[1], hi[1]};
+        *(u32x4*)(base + m * p.N + n) = v;
+      }
+    } else {
+      const int na = n0 + wn * 64 + (2 * jp) * 16 + 4 * g4;
+      if (okm && ok0) *(u32x2*)(base + m * p.N + na) = w0;
+      if (okm && ok1) *(u32x2*)(base + m * p.N + na + 16) = w1;
+    }
+  };
 
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
-    if (n >= p.N) continue;
-    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) bias4 = *(const f32x4*)(p.bias + n);
+  for (int jp = 0; jp < 2; ++jp) {
+    const int nA = n0 + wn * 64 + (2 * jp) * 16 + 4 * g4;
+    const int nB = nA + 16;
+    const bool okA = nA < p.N, okB = nB < p.N;
+    f32x4 biasA = {0.f, 0.f, 0.f, 0.f}, biasB = biasA;
+    if (p.bias) {
+      if (okA) biasA = *(const f32x4*)(p.bias + nA);
+      if (okB) biasB = *(const f32x4*)(p.bias + nB);
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const long long m = m0 + wm * 128 + i * 16 + (lane & 15);
-      if (m >= p.M) continue;
-      f32x4 v = acc[j][i] + bias4;
-      const long long e = m * p.N + n;
+      const bool okm = m < p.M;
+      f32x4 v[2] = {acc[2 * jp][i] + biasA, acc[2 * jp + 1][i] + biasB};
+      const int nn[2] = {nA, nB};
+      const bool okn[2] = {okA, okB};
 
       if constexpr (EPI == VITSSL_EPI_BF16) {
-        u32x2 w = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-        *(u32x2*)((bf16_t*)p.out0 + e) = w;
-      } else if constexpr (EPI == VITSSL_EPI_F32) {
-        *(f32x4*)((float*)p.out0 + e) = v;
+        const u32x2 w0 = {pack_bf2(v[0][0], v[0][1]), pack_bf2(v[0][2], v[0][3])};
+        const u32x2 w1 = {pack_bf2(v[1][0], v[1][1]), pack_bf2(v[1][2], v[1][3])};
+        store_bf16_pair((bf16_t*)p.out0, m, jp, w0, w1, okA, okB, okm);
       } else if constexpr (EPI == VITSSL_EPI_GELU) {
-        u32x2 w = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-        *(u32x2*)((bf16_t*)p.out0 + e) = w;
-        float mult[4] = {1.f, 1.f, 1.f, 1.f};
-        if (p.drop_on) drop_mult4(p.dk, (unsigned long long)e >> 2, mult);
-        float g0 = gelu_f(bf_lo(w[0])) * mult[0], g1 = gelu_f(bf_hi(w[0])) * mult[1];
-        float g2 = gelu_f(bf_lo(w[1])) * mult[2], g3 = gelu_f(bf_hi(w[1])) * mult[3];
-        u32x2 a = {pack_bf2(g0, g1), pack_bf2(g2, g3)};
-        *(u32x2*)((bf16_t*)p.out1 + e) = a;
-      } else if constexpr (EPI == VITSSL_EPI_RESID) {
-        if (p.drop_on) {
-          float mult[4];
-          drop_mult4(p.dk, (unsigned long long)e >> 2, mult);
-          v[0] *= mult[0]; v[1] *= mult[1]; v[2] *= mult[2]; v[3] *= mult[3];
+        u32x2 w[2], a[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          w[h] = u32x2{pack_bf2(v[h][0], v[h][1]), pack_bf2(v[h][2], v[h][3])};
+          float mult[4] = {1.f, 1.f, 1.f, 1.f};
+          if (p.drop_on) drop_mult4(p.dk, (unsigned long long)(m * p.N + nn[h]) >> 2, mult);
+          const float g0 = gelu_f(bf_lo(w[h][0])) * mult[0], g1 = gelu_f(bf_hi(w[h][0])) * mult[1];
+          const float g2 = gelu_f(bf_lo(w[h][1])) * mult[2], g3 = gelu_f(bf_hi(w[h][1])) * mult[3];
+          a[h] = u32x2{pack_bf2(g0, g1), pack_bf2(g2, g3)};
         }
-        const f32x4 res = *(const f32x4*)((const float*)p.aux + e);
-        v += res;
-        *(f32x4*)((float*)p.out0 + e) = v;
+        store_bf16_pair((bf16_t*)p.out0, m, jp, w[0], w[1], okA, okB, okm);
+        store_bf16_pair((bf16_t*)p.out1, m, jp, a[0], a[1], okA, okB, okm);
       } else if constexpr (EPI == VITSSL_EPI_DGELU) {
-        const u32x2 u = *(const u32x2*)((const bf16_t*)p.aux + e);
-        float mult[4] = {1.f, 1.f, 1.f, 1.f};
-        if (p.drop_on) drop_mult4(p.dk, (unsigned long long)e >> 2, mult);
-        v[0] *= mult[0] * dgelu_f(bf_lo(u[0]));
-        v[1] *= mult[1] * dgelu_f(bf_hi(u[0]));
-        v[2] *= mult[2] * dgelu_f(bf_lo(u[1]));
-        v[3] *= mult[3] * dgelu_f(bf_hi(u[1]));
-        u32x2 w = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-        *(u32x2*)((bf16_t*)p.out0 + e) = w;
-      } else if constexpr (EPI == VITSSL_EPI_EMBED) {
-        const long long img = m / p.embed.tokens;
-        const int rin = (int)(m - img * p.embed.tokens);
-        if (p.embed.mask && p.embed.mask[m]) v = *(const f32x4*)(p.embed.mask_token + n);
-        const f32x4 pos = *(const f32x4*)(p.embed.pos + (long long)(p.embed.tok_offset + rin) * p.N + n);
-        v += pos;
-        const long long orow = img * p.embed.out_tokens + p.embed.tok_offset + rin;
-        *(f32x4*)((float*)p.out0 + orow * p.N + n) = v;
+        u32x2 w[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          u32x2 u = {0u, 0u};
+          if (okm && okn[h]) u = *(const u32x2*)((const bf16_t*)p.aux + m * p.N + nn[h]);
+          float mult[4] = {1.f, 1.f, 1.f, 1.f};
+          if (p.drop_on) drop_mult4(p.dk, (unsigned long long)(m * p.N + nn[h]) >> 2, mult);
+          v[h][0] *= mult[0] * dgelu_f(bf_lo(u[0]));
+          v[h][1] *= mult[1] * dgelu_f(bf_hi(u[0]));
+          v[h][2] *= mult[2] * dgelu_f(bf_lo(u[1]));
+          v[h][3] *= mult[3] * dgelu_f(bf_hi(u[1]));
+          w[h] = u32x2{pack_bf2(v[h][0], v[h][1]), pack_bf2(v[h][2], v[h][3])};
+        }
+        store_bf16_pair((bf16_t*)p.out0, m, jp, w[0], w[1], okA, okB, okm);
+      } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (!(okm && okn[h])) continue;
+          const long long e = m * p.N + nn[h];
+          if constexpr (EPI == VITSSL_EPI_F32) {
+            *(f32x4*)((float*)p.out0 + e) = v[h];
+          } else if constexpr (EPI == VITSSL_EPI_RESID) {
+            if (p.drop_on) {
+              float mult[4];
+              drop_mult4(p.dk, (unsigned long long)e >> 2, mult);
+              v[h][0] *= mult[0]; v[h][1] *= mult[1]; v[h][2] *= mult[2]; v[h][3] *= mult[3];
+            }
+            v[h] += *(const f32x4*)((const float*)p.aux + e);
+            *(f32x4*)((float*)p.out0 + e) = v[h];
+          } else if constexpr (EPI == VITSSL_EPI_EMBED) {
+            const long long img = m / p.embed.tokens;
+            const int rin = (int)(m - img * p.embed.tokens);
+            if (p.embed.mask && p.embed.mask[m]) v[h] = *(const f32x4*)(p.embed.mask_token + nn[h]);
+            v[h] += *(const f32x4*)(p.embed.pos + (long long)(p.embed.tok_offset + rin) * p.N + nn[h]);
+            const long long orow = img * p.embed.out_tokens + p.embed.tok_offset + rin;
+            *(f32x4*)((float*)p.out0 + orow * p.N + nn[h]) = v[h];
+          }
+        }
       }
       if (p.colsum) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) csum[j][r] += v[r];
+        for (int h = 0; h < 2; ++h)
+          if (okm && okn[h]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) csum[2 * jp + h][r] += v[h][r];
+          }
       }
     }
   }
@@ -213,21 +307,70 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_nt_kernel(NtParams p) {
   }
 }
 
-template <int EPI>
-int launch_nt(const NtParams& p, hipStream_t s) {
+template <int EPI, typename CFG>
+int launch_cfg(NtParams p, hipStream_t s) {
   static bool attr_done = false;  // idempotent; a benign race sets the same value
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
+  if (!attr_done && CFG::LDS_BYTES > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, CFG>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       CFG::LDS_BYTES);
     if (e != hipSuccess) {
-      vitssl_set_error("gemm_nt: cannot raise dynamic LDS to %d: %s", NT_LDS_BYTES, hipGetErrorString(e));
+      vitssl_set_error("gemm_nt: cannot raise dynamic LDS to %d: %s", CFG::LDS_BYTES, hipGetErrorString(e));
       return VITSSL_ERR_LAUNCH;
     }
     attr_done = true;
   }
-  hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(p.tiles_m * p.tiles_n), dim3(NT_THREADS), NT_LDS_BYTES, s, p);
+  p.tiles_m = (int)ceil_div64(p.M, CFG::BM);
+  p.tiles_n = (int)ceil_div64(p.N, CFG::BN);
+  const int want = (int)((2 * 1024 * 1024) / ((long long)CFG::BN * p.K * 2));   // panels of a group <= ~2 MiB of L2
+  if (p.tiles_n <= 4) p.group_n = p.tiles_n;
+  else if (want <= 2) p.group_n = 2;
+  else if (p.tiles_n % 6 == 0 && want >= 6) p.group_n = 6;
+  else if (p.tiles_n % 4 == 0) p.group_n = 4;
+  else if (p.tiles_n % 3 == 0) p.group_n = 3;
+  else p.group_n = want < 4 ? want : 4;
+  {
+    static int knob = -1;
+    if (knob < 0) {
+      const char* e = getenv("VITSSL_NT_STAGGER");
+      knob = e ? atoi(e) : 0;   // measured: no gain (per-CU memory throughput, not lock-step bursts, bounds the epilogue)
+    }
+    const bool heavy = EPI == VITSSL_EPI_GELU || EPI == VITSSL_EPI_DGELU || EPI == VITSSL_EPI_RESID || EPI == VITSSL_EPI_F32;
+    const int nk = p.K / CFG::BK;
+    p.stagger = (knob && heavy && p.tiles_m * p.tiles_n > 256) ? (nk * knob + 5) / 6 : 0;
+  }
+  hipLaunchKernelGGL((gemm_nt_kernel<EPI, CFG>), dim3(p.tiles_m * p.tiles_n), dim3(CFG::THREADS), CFG::LDS_BYTES, s, p);
   VS_CHECK_LAUNCH("gemm_nt");
   return VITSSL_OK;
+}
+
+// 0 = auto, 1 = always BIG, 2 = always SMALL (VITSSL_NT_TILE, developer knob)
+int nt_tile_override() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("VITSSL_NT_TILE");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
+template <int EPI>
+int launch_nt(const NtParams& p, hipStream_t s) {
+  int mode = nt_tile_override();
+  bool small;
+  if (mode == 1) small = false;
+  else if (mode == 2) small = true;
+  else {
+    // heavy epilogues want co-resident workgroups; so do grids that fill the 256 CUs badly
+    const long long big_tiles = ceil_div64(p.M, 256) * ceil_div64(p.N, 256);
+    const double rounds = (double)big_tiles / 256.0;
+    const double eff = rounds / (double)((long long)(rounds + 0.999999));
+    // Measured on MI355X (tools/bench_gemm.py, round 1): SMALL loses 10-25 % on every
+    // ViT-B shape, heavy epilogues included (co-resident workgroups start in lock-step, so
+    // their epilogues still coincide).  It only pays for tiny grids.
+    (void)eff;
+    small = big_tiles < 64;
+  }
+  return small ? launch_cfg<EPI, NtSmall>(p, s) : launch_cfg<EPI, NtBig>(p, s);
 }
 
 }  // namespace
@@ -235,7 +378,7 @@ int launch_nt(const NtParams& p, hipStream_t s) {
 extern "C" int vitssl_gemm_bf16_nt(const vitssl_gemm_t* g, void* stream) {
   VS_CHECK_ARG(g && g->A && g->B && g->out0, "gemm_nt: null operand");
   VS_CHECK_ARG(g->M > 0 && g->N > 0 && g->K > 0, "gemm_nt: empty problem M=%lld N=%d K=%d", (long long)g->M, g->N, g->K);
-  VS_CHECK_ARG(g->K % BK == 0, "gemm_nt: K=%d must be a multiple of %d", g->K, BK);
+  VS_CHECK_ARG(g->K % 64 == 0, "gemm_nt: K=%d must be a multiple of 64", g->K);
   VS_CHECK_ARG(g->N % 4 == 0, "gemm_nt: N=%d must be a multiple of 4", g->N);
   VS_CHECK_ARG((unsigned long long)g->M * g->K * 2ull < (1ull << 31) && (unsigned long long)g->N * g->K * 2ull < (1ull << 31),
                "gemm_nt: operand larger than 2 GiB (M=%lld N=%d K=%d)", (long long)g->M, g->N, g->K);
@@ -253,8 +396,7 @@ extern "C" int vitssl_gemm_bf16_nt(const vitssl_gemm_t* g, void* stream) {
   p.dk = make_drop_key(g->drop);
   p.drop_on = p.dk.thr != 0;
   p.embed = g->embed;
-  p.tiles_m = (int)ceil_div64(g->M, BM);
-  p.tiles_n = (int)ceil_div64(g->N, BN);
+  p.tiles_m = p.tiles_n = p.group_n = 0;   // set per tile configuration in launch_cfg
   hipStream_t s = (hipStream_t)stream;
   switch (g->epilogue) {
     case VITSSL_EPI_BF16: return launch_nt<VITSSL_EPI_BF16>(p, s);

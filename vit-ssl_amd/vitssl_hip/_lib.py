@@ -40,7 +40,7 @@ PROTOTYPES = {
     "vitssl_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, Dropout, _i64, _i, _vp],
     "vitssl_grad_mask_cast": [_vp, _vp, _vp, Dropout, _i64, _i, _vp],
     "vitssl_gemm_bf16_nt": [C.POINTER(Gemm), _vp],
-    "vitssl_gemm_bf16_tn": [_vp, _vp, _vp, _i64, _i, _i, _vp],
+    "vitssl_gemm_bf16_tn": [_vp, _vp, _vp, _i64, _i, _i, _vp, _i64, _vp],
     "vitssl_attn_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "vitssl_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "vitssl_patchify_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
@@ -89,6 +89,8 @@ def lib():
     l.vitssl_last_error.argtypes = []
     l.vitssl_version.restype = C.c_int
     l.vitssl_version.argtypes = []
+    l.vitssl_gemm_tn_workspace_floats.restype = C.c_int64
+    l.vitssl_gemm_tn_workspace_floats.argtypes = [C.c_int64, C.c_int, C.c_int]
     for name, args in PROTOTYPES.items():
         fn = getattr(l, name)  # AttributeError if the symbol is missing
         fn.restype = C.c_int

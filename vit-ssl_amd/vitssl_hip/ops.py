@@ -130,14 +130,36 @@ def gemm_nt(A, B, out0, epilogue, bias=None, aux=None, out1=None, colsum=None, d
     _prof_end(ev, f"gemm_nt[epi{epilogue}] {M}x{N}x{K}", 2.0 * M * N * K)
 
 
-def gemm_tn(A, B, Cacc):
+_TN_WS = {}
+
+
+def _tn_workspace(device, floats):
+    """Per-device slab workspace for the split-M wgrad combine (grown on demand, reused by
+    every launch: launches on one stream are ordered, the reduce kernel drains the slabs
+    before the next wgrad writes them)."""
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    ws = _TN_WS.get(key)
+    if ws is None or ws.numel() < floats:
+        ws = torch.empty(max(floats, 1 << 20), dtype=F32, device=device)
+        _TN_WS[key] = ws
+    return ws
+
+
+def gemm_tn(A, B, Cacc, atomic=False):
     """Cacc[N1,N2] (fp32) += A[M,N1]^T @ B[M,N2]."""
     M, N1 = A.shape
     M2, N2 = B.shape
     if M != M2:
         raise L.VitsslError(f"gemm_tn: M mismatch {M} vs {M2}")
+    a, b, c = _chk(A, BF16, "A"), _chk(B, BF16, "B"), _chk(Cacc, F32, "C", (N1, N2))
+    if atomic:
+        wsp, wsn = C.c_void_p(0), 0
+    else:
+        wsn = int(L.lib().vitssl_gemm_tn_workspace_floats(M, N1, N2))
+        ws = _tn_workspace(A.device, wsn)
+        wsp, wsn = C.c_void_p(ws.data_ptr()), ws.numel()
     ev = _prof_begin()
-    call("vitssl_gemm_bf16_tn", _chk(A, BF16, "A"), _chk(B, BF16, "B"), _chk(Cacc, F32, "C", (N1, N2)), M, N1, N2, _stream())
+    call("vitssl_gemm_bf16_tn", a, b, c, M, N1, N2, wsp, wsn, _stream())
     _prof_end(ev, f"gemm_tn {N1}x{N2}x{M}", 2.0 * M * N1 * N2)
 
 
