@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path on one GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use cuda:0")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -101,8 +103,8 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    dev = torch.device(f"cuda:{local_rank}")
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+    dev = torch.device("cuda:0" if args.share_gpu else f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
 
     from vit_core.ssl.simmim import SimMIMViT
@@ -126,6 +128,7 @@ def main():
     torch.manual_seed(1000 + rank)                          # masks / dropout seeds are rank-local
 
     def sync():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

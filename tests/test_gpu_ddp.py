@@ -1,0 +1,88 @@
+"""Data-parallel correctness on the GPU: 2 ranks (gloo rendezvous, both on cuda:0 --
+RCCL refuses two ranks on one device; the driver's multi-GPU run uses nccl) each take
+half of a batch.  After one fused step (a) both ranks hold bit-identical weights,
+(b) the all-reduced, 1/world-scaled gradients equal a single-process step on the whole
+batch with the same masks, within the bf16 tolerance of test_gpu_models."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build(dev):
+    from vit_core.ssl.simmim import SimMIMViT
+    torch.manual_seed(7)
+    return SimMIMViT(num_blocks=2, input_shape=(3, 32, 32), embed_dim=128, patch_size=8, num_heads=2, mlp_dim=192,
+                     dropout=0.0, mask_ratio=0.6).to(dev).train()
+
+
+def _worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "vit-ssl_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from _util import rel_l2
+        from vit_core.ssl.simmim.masking import draw_mask
+        from vitssl_hip.engine import GradReducer
+        from vitssl_hip.optim import FusedAdamW
+        dev = torch.device("cuda:0")
+        g = torch.Generator().manual_seed(3)
+        x = torch.rand(8, 3, 32, 32, generator=g).to(dev)
+        torch.manual_seed(11)
+        mask = draw_mask(8, 16, 0.6)
+        per = 8 // world
+
+        model = _build(dev)
+        store = model.flat_store()
+        if rank == 1:                                   # prove the broadcast matters
+            store.flat.add_(1.0)
+        dist.broadcast(store.flat, 0)
+        store.mark_dirty()
+        red = GradReducer(store.gflat, bucket_mb=0.5)
+        opt = FusedAdamW(store, lr=1e-3, weight_decay=1e-3)
+        sl = slice(rank * per, (rank + 1) * per)
+        loss = model.train_step(x[sl], opt, red, mask_cpu=mask[sl])
+        torch.cuda.synchronize()
+        assert len(red.launched) >= 2
+        flats = [torch.empty_like(store.flat) for _ in range(world)]
+        dist.all_gather(flats, store.flat)
+        assert torch.equal(flats[0], flats[1])          # replicas stay bit-identical
+        grads = store.gflat * red.grad_scale
+        losses = [torch.zeros(1, device=dev) for _ in range(world)]
+        dist.all_gather(losses, loss.reshape(1))
+
+        if rank == 0:                                   # single-process reference on the whole batch
+            ref = _build(dev)
+            rstore = ref.flat_store()
+            ropt = FusedAdamW(rstore, lr=1e-3, weight_decay=1e-3)
+            rloss = ref.train_step(x, ropt, None, mask_cpu=mask)
+            torch.cuda.synchronize()
+            assert abs(float(sum(losses)) / world - float(rloss)) < 1e-4
+            for n in rstore.names:
+                o, cnt = rstore.offsets[n]
+                assert rel_l2(grads[o:o + cnt], rstore.gflat[o:o + cnt]) < 2e-2, n
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_equal_single_process(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))

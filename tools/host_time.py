@@ -26,3 +26,16 @@ print("host enqueue ms/step:", [round(h, 2) for h in host], " total ms/step:", [
 import cProfile, pstats
 pr = cProfile.Profile(); pr.enable(); m.train_step(x, opt); pr.disable(); torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+
+# ---- same loop without per-step sync (the host runs ahead, like bench.py)
+for label, xin in (("device rand", x), ("cpu-generator rand", torch.rand(256, 3, 224, 224, generator=torch.Generator().manual_seed(42)).to(dev))):
+    for _ in range(3):
+        m.train_step(xin, opt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        m.train_step(xin, opt)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"no-sync loop [{label}]: enqueue {(t1-t0)/20*1e3:.2f} ms/step, total {(t2-t0)/20*1e3:.2f} ms/step")

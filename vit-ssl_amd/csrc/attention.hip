@@ -20,9 +20,10 @@
 // (ds_read_b64_tr_b16): 128-byte rows, 16-byte chunk index XORed with ((row>>1)&3)<<1;
 // both read kinds are bank-conflict free.
 //
-// Backward = 3 launches: delta = rowsum(dO*O); dK/dV (each wave owns 32 keys, sweeps
-// queries); dQ (each wave owns 16-query tiles, sweeps keys).  P is recomputed from the
-// saved log-sum-exp; nothing of size N^2 ever reaches HBM.
+// Backward = 2 launches: dQ (each wave owns pairs of 16-query tiles, sweeps keys; it also
+// produces delta = rowsum(dO*O) for its queries from the fragments it already holds) and
+// dK/dV (each wave owns 32 keys, sweeps queries).  P is recomputed from the saved
+// log-sum-exp; nothing of size N^2 ever reaches HBM.
 #include "common.h"
 
 namespace {
@@ -205,28 +206,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
   }
 }
 
-// ------------------------------------------------------------------ backward: delta
-__global__ void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, float* __restrict__ delta,
-                                  int B, int N, int H) {
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // (b, q, h)
-  const long long total = (long long)B * N * H;
-  if (idx >= total) return;
-  const int h = (int)(idx % H);
-  const long long bq = idx / H;
-  const int q = (int)(bq % N);
-  const long long b = bq / N;
-  const u32x4* po = (const u32x4*)(o + idx * DH);
-  const u32x4* pd = (const u32x4*)(dout + idx * DH);
-  float acc = 0.f;
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const u32x4 a = po[c], d = pd[c];
-#pragma unroll
-    for (int w = 0; w < 4; ++w) acc += bf_lo(a[w]) * bf_lo(d[w]) + bf_hi(a[w]) * bf_hi(d[w]);
-  }
-  delta[(b * H + h) * N + q] = acc;
-}
-
 // ------------------------------------------------------------------ backward: dK, dV
 // grid = B*H, 512 threads: wave w owns keys [32w, 32w+32).  Q and dO tiles in LDS.
 template <int NS>
@@ -334,9 +313,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16_t* __restr
 // grid = B*H, 256 threads (2 workgroups per CU): waves own PAIRS of 16-query tiles;
 // K and V tiles in LDS, each fragment read feeds both tiles.
 template <int NS>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
-                                                             const float* __restrict__ lse, const float* __restrict__ delta,
-                                                             bf16_t* __restrict__ dqkv, int N, int H) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ outp,
+                                                             const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                             float* __restrict__ delta, bf16_t* __restrict__ dqkv, int N, int H) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int Np = 32 * NS;
   constexpr int NKT = 2 * NS;
@@ -348,6 +327,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
   const bf16_t* kg = qg + (long long)H * DH;
   const bf16_t* vg = kg + (long long)H * DH;
   const bf16_t* dog = dout + (long long)b * N * (H * DH) + h * DH;
+  const bf16_t* og = outp + (long long)b * N * (H * DH) + h * DH;
   load_tile(Kt, kg, stride, N, Np, threadIdx.x, 256);
   load_tile(Vt, vg, stride, N, Np, threadIdx.x, 256);
   __syncthreads();
@@ -369,7 +349,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
       df[t][0] = glb_frag(dog, (long long)H * DH, q[t], 0, N, lane);
       df[t][1] = glb_frag(dog, (long long)H * DH, q[t], 1, N, lane);
       l[t] = q[t] < N ? lse[((long long)b * H + h) * N + q[t]] : INFINITY;
-      dl[t] = q[t] < N ? delta[((long long)b * H + h) * N + q[t]] : 0.f;
+      // delta[q] = sum_d dO[q][d] O[q][d]: this lane holds 16 of the 64 d of its query
+      // (fragment positions 32kk + 8g + j); reduce over the 4 lane groups.
+      float part = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const u32x4 ov = __builtin_bit_cast(u32x4, glb_frag(og, (long long)H * DH, q[t], kk, N, lane));
+        const u32x4 dv = __builtin_bit_cast(u32x4, df[t][kk]);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) part += bf_lo(ov[w]) * bf_lo(dv[w]) + bf_hi(ov[w]) * bf_hi(dv[w]);
+      }
+      part += __shfl_xor(part, 16, 64);
+      part += __shfl_xor(part, 32, 64);
+      dl[t] = part;
+      if (q[t] < N && g == 0) delta[((long long)b * H + h) * N + q[t]] = part;
     }
     f32x4 ds0[NKT], ds1[NKT];
 #pragma unroll
@@ -450,17 +443,17 @@ int launch_fwd(const bf16_t* qkv, bf16_t* out, float* lse, float* probs, int B, 
 }
 
 template <int NS>
-int launch_bwd(const bf16_t* qkv, const bf16_t* dout, const float* lse, const float* delta, bf16_t* dqkv, int B, int N,
-               int H, hipStream_t s) {
+int launch_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, float* delta, bf16_t* dqkv, int B,
+               int N, int H, hipStream_t s) {
   static bool done_kv = false, done_q = false;
+  const int lds_q = 2 * NS * 32 * ROWB;
+  if (int rc = ensure_lds(attn_bwd_dq_kernel<NS>, lds_q, &done_q, "attn_bwd_dq")) return rc;
+  hipLaunchKernelGGL(attn_bwd_dq_kernel<NS>, dim3(B * H), dim3(256), lds_q, s, qkv, out, dout, lse, delta, dqkv, N, H);
+  VS_CHECK_LAUNCH("attn_bwd_dq");
   const int lds_kv = 2 * NS * 32 * ROWB + 2 * NS * 32 * 4;
   if (int rc = ensure_lds(attn_bwd_dkv_kernel<NS>, lds_kv, &done_kv, "attn_bwd_dkv")) return rc;
   hipLaunchKernelGGL(attn_bwd_dkv_kernel<NS>, dim3(B * H), dim3(512), lds_kv, s, qkv, dout, lse, delta, dqkv, N, H);
   VS_CHECK_LAUNCH("attn_bwd_dkv");
-  const int lds_q = 2 * NS * 32 * ROWB;
-  if (int rc = ensure_lds(attn_bwd_dq_kernel<NS>, lds_q, &done_q, "attn_bwd_dq")) return rc;
-  hipLaunchKernelGGL(attn_bwd_dq_kernel<NS>, dim3(B * H), dim3(256), lds_q, s, qkv, dout, lse, delta, dqkv, N, H);
-  VS_CHECK_LAUNCH("attn_bwd_dq");
   return VITSSL_OK;
 }
 
@@ -499,11 +492,7 @@ extern "C" int vitssl_attn_bwd(const void* qkv, const void* out, const void* dou
   VS_CHECK_ARG(qkv && out && dout && lse && dqkv && delta_ws, "attn_bwd: null pointer");
   if (int rc = check_attn_shape("attn_bwd", B, N, H, dh)) return rc;
   hipStream_t s = (hipStream_t)stream;
-  const long long total = (long long)B * N * H;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const bf16_t*)out,
-                     (const bf16_t*)dout, delta_ws, B, N, H);
-  VS_CHECK_LAUNCH("attn_delta");
-#define VS_CALL(NS) launch_bwd<NS>((const bf16_t*)qkv, (const bf16_t*)dout, lse, delta_ws, (bf16_t*)dqkv, B, N, H, s)
+#define VS_CALL(NS) launch_bwd<NS>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, delta_ws, (bf16_t*)dqkv, B, N, H, s)
   VS_NS_SWITCH((N + 31) / 32, VS_CALL)
 #undef VS_CALL
 }

@@ -115,20 +115,29 @@ __global__ void embed_bwd_kernel(const float* __restrict__ dtok, const unsigned 
   const int b1 = min(B, b0 + per);
   for (int c = threadIdx.x * 4; c < D; c += blockDim.x * 4) {
     f32x4 pos = {0.f, 0.f, 0.f, 0.f}, mt = pos, bias = pos;
-    for (int b = b0; b < b1; ++b) {
-      const f32x4 v = *(const f32x4*)(dtok + ((long long)b * T_out + t) * D + c);
-      pos += v;
-      if (t >= tok_offset) {
-        const long long m = (long long)b * tokens + (t - tok_offset);
-        const bool masked = mask && mask[m];
-        u32x2 w = {0u, 0u};
-        if (masked) {
-          mt += v;
-        } else {
-          bias += v;
-          w = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+    for (int bb = b0; bb < b1; bb += 4) {
+      // 4 images per trip: independent loads in flight (the kernel is latency-bound)
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (bb + u < b1) v[u] = *(const f32x4*)(dtok + ((long long)(bb + u) * T_out + t) * D + c);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int b = bb + u;
+        if (b >= b1) break;
+        pos += v[u];
+        if (t >= tok_offset) {
+          const long long m = (long long)b * tokens + (t - tok_offset);
+          const bool masked = mask && mask[m];
+          u32x2 w = {0u, 0u};
+          if (masked) {
+            mt += v[u];
+          } else {
+            bias += v[u];
+            w = u32x2{pack_bf2(v[u][0], v[u][1]), pack_bf2(v[u][2], v[u][3])};
+          }
+          *(u32x2*)(dproj + m * D + c) = w;
         }
-        *(u32x2*)(dproj + m * D + c) = w;
       }
     }
 #pragma unroll
@@ -371,10 +380,12 @@ extern "C" int vitssl_embed_bwd(const float* dtok, const uint8_t* mask, void* dp
   VS_CHECK_ARG(tok_offset == 0 || tok_offset == 1, "embed_bwd: tok_offset must be 0 or 1");
   VS_CHECK_ARG(!mask || dmask_token, "embed_bwd: mask without dmask_token");
   const int T_out = tokens + tok_offset;
+  // few blocks along the batch axis: every block ends with D atomics per accumulator row
+  // (dmask_token / dbias are single rows: contention grows with the block count)
   int bs = 2048 / T_out;
   if (bs < 1) bs = 1;
   if (bs > B) bs = B;
-  if (bs > 64) bs = 64;
+  if (bs > 16) bs = 16;
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(T_out, bs), dim3(EW_THREADS), 0, (hipStream_t)stream, dtok, mask, (bf16_t*)dproj_bf16,
                      dpos, dmask_token, dbias, dcls, B, tokens, tok_offset, D);
   VS_CHECK_LAUNCH("embed_bwd");

@@ -29,19 +29,22 @@
 
 namespace {
 
-template <int BK_, int WM_, int WN_>
+template <int BK_, int WM_, int WN_, int NBUF_ = 2>
 struct NtCfg {
-  static constexpr int BK = BK_, WM = WM_, WN = WN_;
+  static constexpr int BK = BK_, WM = WM_, WN = WN_, NBUF = NBUF_;
   static constexpr int BM = 128 * WM_, BN = 64 * WN_;
   static constexpr int WAVES = WM_ * WN_, THREADS = 64 * WM_ * WN_;
   static constexpr int ROWB = BK_ * 2;                       // bytes per tile row
   static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
   static constexpr int BUF_BYTES = A_BYTES + B_BYTES;
-  static constexpr int LDS_BYTES = 2 * BUF_BYTES;
-  static constexpr int MIN_WAVES_PER_SIMD = (BK_ == 64) ? 2 : 2;
+  static constexpr int LDS_BYTES = NBUF_ * BUF_BYTES;
+  static constexpr int MIN_WAVES_PER_SIMD = 2;
 };
 using NtBig = NtCfg<64, 2, 4>;
 using NtSmall = NtCfg<32, 2, 2>;
+// 256x256 tile, 32-deep stages in a 4-slot LDS ring: three stages (96 KiB per CU) stay in
+// flight behind a counted vmcnt and a raw s_barrier, instead of draining to zero each step.
+using NtDeep = NtCfg<32, 2, 4, 4>;
 
 struct NtParams {
   const bf16_t* A;
@@ -136,23 +139,11 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
     for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / BK;
-  stage_tile<BK, BM, CFG::WAVES>(rsA, smem, m0, 0, p.K, wave, lane);
-  stage_tile<BK, BN, CFG::WAVES>(rsB, smem + CFG::A_BYTES, n0, 0, p.K, wave, lane);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
   const int swz = nt_swz<BK>(lane & 15);           // rows are 16*x + (lane&15)
   const int frag_row = lane & 15;
   const int kq = lane >> 4;
 
-  for (int t = 0; t < nk; ++t) {
-    char* bufA = smem + (t & 1) * CFG::BUF_BYTES;
-    char* bufB = bufA + CFG::A_BYTES;
-    if (t + 1 < nk) {
-      char* nA = smem + ((t + 1) & 1) * CFG::BUF_BYTES;
-      stage_tile<BK, BM, CFG::WAVES>(rsA, nA, m0, (t + 1) * BK, p.K, wave, lane);
-      stage_tile<BK, BN, CFG::WAVES>(rsB, nA + CFG::A_BYTES, n0, (t + 1) * BK, p.K, wave, lane);
-    }
+  auto compute_stage = [&](const char* bufA, const char* bufB) {
 #pragma unroll
     for (int kk = 0; kk < BK / 32; ++kk) {
       const int coff = ((kk * 4 + kq) ^ swz) << 4;
@@ -169,8 +160,54 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
         for (int i = 0; i < 8; ++i)
           acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
     }
+  };
+
+  if constexpr (CFG::NBUF == 2) {
+    stage_tile<BK, BM, CFG::WAVES>(rsA, smem, m0, 0, p.K, wave, lane);
+    stage_tile<BK, BN, CFG::WAVES>(rsB, smem + CFG::A_BYTES, n0, 0, p.K, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+      char* bufA = smem + (t & 1) * CFG::BUF_BYTES;
+      if (t + 1 < nk) {
+        char* nA = smem + ((t + 1) & 1) * CFG::BUF_BYTES;
+        stage_tile<BK, BM, CFG::WAVES>(rsA, nA, m0, (t + 1) * BK, p.K, wave, lane);
+        stage_tile<BK, BN, CFG::WAVES>(rsB, nA + CFG::A_BYTES, n0, (t + 1) * BK, p.K, wave, lane);
+      }
+      compute_stage(bufA, bufA + CFG::A_BYTES);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else {
+    // LDS ring of NBUF stages; stage t lives in slot t % NBUF.  Per wave a stage is
+    // GL = 4 + 2*... DMA instructions (A then B), so "all but the 2 youngest stages
+    // have landed" is vmcnt(2*GL).
+    constexpr int GL = (BM * CFG::ROWB / 1024 + BN * CFG::ROWB / 1024) / CFG::WAVES;
+    static_assert(GL == 4, "counted vmcnt immediates below assume 4 DMA instructions per stage per wave");
+    auto issue = [&](int t) {
+      char* dst = smem + (t % CFG::NBUF) * CFG::BUF_BYTES;
+      stage_tile<BK, BM, CFG::WAVES>(rsA, dst, m0, t * BK, p.K, wave, lane);
+      stage_tile<BK, BN, CFG::WAVES>(rsB, dst + CFG::A_BYTES, n0, t * BK, p.K, wave, lane);
+    };
+    issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 2) issue(2);
+    for (int t = 0; t < nk; ++t) {
+      // stage t must have landed; stages t+1, t+2 (if they exist) may stay in flight
+      const int younger = nk - 1 - t;
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // every wave's share of stage t has landed AND every wave has finished reading
+      // slot (t-1) % NBUF, which the next DMA overwrites
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (t + 3 < nk) issue(t + 3);
+      const char* bufA = smem + (t % CFG::NBUF) * CFG::BUF_BYTES;
+      compute_stage(bufA, bufA + CFG::A_BYTES);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
   }
 
   // ------------------------------------------------------------------ epilogue
@@ -343,7 +380,7 @@ int launch_cfg(NtParams p, hipStream_t s) {
   return VITSSL_OK;
 }
 
-// 0 = auto, 1 = always BIG, 2 = always SMALL (VITSSL_NT_TILE, developer knob)
+// 0 = auto, 1 = always BIG, 2 = always SMALL, 3 = always DEEP (VITSSL_NT_TILE, developer knob)
 int nt_tile_override() {
   static int v = -1;
   if (v < 0) {
@@ -370,6 +407,7 @@ int launch_nt(const NtParams& p, hipStream_t s) {
     (void)eff;
     small = big_tiles < 64;
   }
+  if (mode == 3) return launch_cfg<EPI, NtDeep>(p, s);
   return small ? launch_cfg<EPI, NtSmall>(p, s) : launch_cfg<EPI, NtBig>(p, s);
 }
 

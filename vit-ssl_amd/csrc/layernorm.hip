@@ -75,8 +75,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restr
 }
 
 // HAS_LN = false turns the kernel into the plain "mask + cast + column-sum" of g_res.
-template <int V, bool HAS_LN>
-__global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
+template <int V, bool HAS_LN, bool HAS_CS>
+__global__ __launch_bounds__(LN_THREADS, (V <= 2 || (V == 3 && !HAS_CS)) ? 4 : (V <= 4 ? 3 : 1)) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* g_res,
                                                             float* g_out, bf16_t* __restrict__ gm, float* __restrict__ dgamma,
@@ -100,20 +100,21 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
     f32x4 dx[V];
     if constexpr (HAS_LN) {
       const float mu = mean[row], rs = rstd[row];
-      f32x4 xh[V], dyg[V];
+      f32x4 xh[V];
+      u32x2 dyp[V];   // dy kept packed (bf16) between the two passes: fewer live registers
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int v = 0; v < V; ++v) {
         const int c4 = lane + 64 * v;
         if (c4 < c4n) {
-          const u32x2 w = *(const u32x2*)(dy + row * cols + 4 * c4);
-          const f32x4 d = {bf_lo(w[0]), bf_hi(w[0]), bf_lo(w[1]), bf_hi(w[1])};
+          dyp[v] = *(const u32x2*)(dy + row * cols + 4 * c4);
+          const f32x4 d = {bf_lo(dyp[v][0]), bf_hi(dyp[v][0]), bf_lo(dyp[v][1]), bf_hi(dyp[v][1])};
           xh[v] = (*(const f32x4*)(x + row * cols + 4 * c4) - mu) * rs;
-          dyg[v] = d * g[v];
+          const f32x4 dyg = d * g[v];
           acc_dg[v] += d * xh[v];
           acc_db[v] += d;
-          s1 += dyg[v][0] + dyg[v][1] + dyg[v][2] + dyg[v][3];
-          const f32x4 t = dyg[v] * xh[v];
+          s1 += dyg[0] + dyg[1] + dyg[2] + dyg[3];
+          const f32x4 t = dyg * xh[v];
           s2 += t[0] + t[1] + t[2] + t[3];
         }
       }
@@ -123,7 +124,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
       for (int v = 0; v < V; ++v) {
         const int c4 = lane + 64 * v;
         if (c4 < c4n) {
-          dx[v] = (dyg[v] - m1 - xh[v] * m2) * rs;
+          const f32x4 d = {bf_lo(dyp[v][0]), bf_hi(dyp[v][0]), bf_lo(dyp[v][1]), bf_hi(dyp[v][1])};
+          dx[v] = (d * g[v] - m1 - xh[v] * m2) * rs;
           if (g_res) dx[v] += *(const f32x4*)(g_res + row * cols + 4 * c4);
           *(f32x4*)(g_out + row * cols + 4 * c4) = dx[v];
         }
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
           }
           u32x2 w = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
           *(u32x2*)(gm + row * cols + 4 * c4) = w;
-          acc_cs[v] += o;
+          if (HAS_CS) acc_cs[v] += o;
         }
       }
     }
@@ -157,6 +159,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
 #pragma unroll
   for (int qty = 0; qty < 3; ++qty) {
     if (qty < 2 && !HAS_LN) continue;
+    if (qty == 2 && !HAS_CS) continue;
     float* target = qty == 0 ? dgamma : (qty == 1 ? dbeta : gm_colsum);
     if (!target) continue;   // kernel-argument uniform
 #pragma unroll
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const bf16_t* __rest
 
 inline int ln_grid(long long rows) {
   long long g = (rows + 3) / 4;
-  if (g > 1024) g = 1024;
+  if (g > 2048) g = 2048;
   if (g < 1) g = 1;
   return (int)g;
 }
@@ -188,9 +191,15 @@ int launch_ln_bwd(const void* dy, const float* x, const float* mean, const float
   DropKey dk = make_drop_key(drop);
   const int on = dk.thr != 0;
   const int grid = ln_grid(rows);
-#define VS_LNB(V)                                                                                                     \
-  hipLaunchKernelGGL((ln_bwd_kernel<V, HAS_LN>), dim3(grid), dim3(LN_THREADS), 0, s, (const bf16_t*)dy, x, mean, rstd, \
-                     gamma, g_res, g_out, (bf16_t*)gm, dgamma, dbeta, gm_colsum, dk, on, (long long)rows, cols)
+#define VS_LNB(V)                                                                                                        \
+  do {                                                                                                                   \
+    if (gm_colsum)                                                                                                       \
+      hipLaunchKernelGGL((ln_bwd_kernel<V, HAS_LN, true>), dim3(grid), dim3(LN_THREADS), 0, s, (const bf16_t*)dy, x, mean, \
+                         rstd, gamma, g_res, g_out, (bf16_t*)gm, dgamma, dbeta, gm_colsum, dk, on, (long long)rows, cols); \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((ln_bwd_kernel<V, HAS_LN, false>), dim3(grid), dim3(LN_THREADS), 0, s, (const bf16_t*)dy, x, mean, \
+                         rstd, gamma, g_res, g_out, (bf16_t*)gm, dgamma, dbeta, gm_colsum, dk, on, (long long)rows, cols); \
+  } while (0)
   if (cols <= 256) VS_LNB(1);
   else if (cols <= 512) VS_LNB(2);
   else if (cols <= 768) VS_LNB(3);

@@ -35,3 +35,28 @@ def as_f32(x: torch.Tensor) -> torch.Tensor:
     if x.dtype != F32:
         x = x.float()
     return x.contiguous()
+
+
+class StepPacer:
+    """Bounds how far the host may run ahead of the GPU (in whole train steps).
+
+    Measured on MI355X / ROCm 7.2 (tools/host_time.py): with ~330 launches per step and an
+    unbounded launch queue the GPU itself runs 12-25 % slower (the runtime's in-flight
+    packet/signal pool is exhausted and refilled in bursts); with a sync after every step
+    the GPU idles while the host draws the next masks.  Keeping at most `depth` steps in
+    flight gets both right."""
+
+    def __init__(self, depth=None):
+        if depth is None:
+            depth = int(os.environ.get("VITSSL_STEP_LOOKAHEAD", "1"))
+        self.depth = max(0, depth)
+        self.events = []
+
+    def begin_step(self):
+        while len(self.events) > self.depth:
+            self.events.pop(0).synchronize()
+
+    def end_step(self):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.events.append(ev)

@@ -234,6 +234,9 @@ class DINOViT(nn.Module):
         R.require_gpu(views[0], "DINOViT.train_step")
         rt = self.runtime(views[0].device)
         st = rt.stores["student"]
+        if getattr(self, "_pacer", None) is None:
+            object.__setattr__(self, "_pacer", R.StepPacer())
+        self._pacer.begin_step()
         with torch.no_grad():
             st.gflat.zero_()
             if reducer is not None:
@@ -255,4 +258,6 @@ class DINOViT(nn.Module):
             optimizer.step_flat(gscale)
             self.momentum_update_teacher(teacher_momentum)
             self.last_teacher, self.last_student = teacher, student
-            return loss[0].clone()
+            out = loss[0].clone()
+            self._pacer.end_step()
+            return out

@@ -216,6 +216,9 @@ class SimMIMViT(nn.Module):
         R.require_gpu(x, "SimMIMViT.train_step")
         rt = self.runtime(x.device)
         st = rt.store
+        if getattr(self, "_pacer", None) is None:
+            object.__setattr__(self, "_pacer", R.StepPacer())
+        self._pacer.begin_step()
         with torch.no_grad():
             st.gflat.zero_()
             if reducer is not None:
@@ -233,4 +236,6 @@ class SimMIMViT(nn.Module):
                 gscale = reducer.grad_scale
             optimizer.step_flat(gscale)
             self.last_pred, self.last_targets = pred, targets
-            return loss_sum[0] / n
+            loss = loss_sum[0] / n
+            self._pacer.end_step()
+            return loss
