@@ -1,0 +1,93 @@
+"""BASELINE.json full-size configurations, checked through size-independent properties
+(the CPU oracle would need minutes per step at these sizes):
+  * masks: exactly int(N*ratio) masked patches per image, targets bit-equal to a torch
+    gather of the unfolded image, prediction rows in ascending (b, n) order;
+  * the fused loss equals mean|pred - target| recomputed by torch on the returned tensors;
+  * linearity of backward: gradients scale exactly with the upstream gradient scale;
+  * optimisation sanity: a few fused steps on one fixed batch reduce the loss;
+  * eval-mode forward is deterministic and batch-independent."""
+import pytest
+import torch
+
+from _util import rel_l2, max_abs
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+CFGS = {
+    "vit_s_simmim_b256": dict(D=384, L=12, H=6, F=1536, B=256),     # BASELINE configs[1]
+    "vit_b_simmim_b64": dict(D=768, L=12, H=12, F=3072, B=64),      # configs[2] model at a test-sized batch
+}
+
+
+@pytest.mark.parametrize("name", sorted(CFGS))
+def test_simmim_fullsize_properties(name):
+    from vit_core.ssl.simmim import SimMIMViT
+    from vitssl_hip.optim import FusedAdamW
+    c = CFGS[name]
+    torch.manual_seed(42)
+    model = SimMIMViT(num_blocks=c["L"], input_shape=(3, 224, 224), embed_dim=c["D"], patch_size=16, num_heads=c["H"],
+                      mlp_dim=c["F"], dropout=0.0, mask_ratio=0.6).to(DEV).train()
+    B = c["B"]
+    x = torch.rand(B, 3, 224, 224, generator=torch.Generator().manual_seed(1)).to(DEV)
+    torch.manual_seed(5)
+    pred, tgt, mask = model(x, return_bool_mask=True)
+    m2 = mask[..., 0]
+    assert m2.shape == (B, 196) and bool((m2.sum(1) == 117).all())                 # int(196 * 0.6) per image
+    patches = torch.nn.functional.unfold(x, 16, stride=16).permute(0, 2, 1)       # torch's own unfold as the checker
+    assert torch.equal(tgt, patches[m2])                                           # bit-exact, ascending (b, n)
+    assert pred.shape == (B * 117, 768) and bool(torch.isfinite(pred).all())
+    loss = torch.nn.functional.l1_loss(pred, tgt)
+    loss.backward()
+    g1 = {k: p.grad.clone() for k, p in model.named_parameters()}
+    # linearity: backward of 3*loss gives 3*grad (same masks via the same seed)
+    model.zero_grad(set_to_none=True)
+    torch.manual_seed(5)
+    pred2, tgt2 = model(x)
+    assert torch.equal(pred2, pred)
+    (3.0 * torch.nn.functional.l1_loss(pred2, tgt2)).backward()
+    for k, p in model.named_parameters():
+        assert rel_l2(p.grad, 3.0 * g1[k]) < 2e-2, k                               # bf16 operand rounding of the scaled dY
+    # fused step: same loss value, and training on one fixed batch goes down
+    opt = FusedAdamW(model.flat_store(), lr=1e-4, weight_decay=1e-3)
+    torch.manual_seed(5)
+    l0 = float(model.train_step(x, opt))
+    assert abs(l0 - float(loss)) < 1e-4 * abs(float(loss))
+    assert abs(float((model.last_pred - model.last_targets).abs().mean()) - l0) < 1e-5
+    for _ in range(6):
+        torch.manual_seed(5)
+        l1 = float(model.train_step(x, opt))
+    assert l1 < l0
+    # eval: deterministic + batch independent
+    model.eval()
+    with torch.no_grad():
+        f_all = model.inference_forward(x[:8])
+        f_again = model.inference_forward(x[:8])
+        f_one = torch.cat([model.inference_forward(x[i:i + 1]) for i in range(8)])
+    assert torch.equal(f_all, f_again) and max_abs(f_all, f_one) < 1e-4
+
+
+def test_dino_fullsize_step():
+    """BASELINE configs[3] shapes: ViT-B/16, 2 x 224^2 + 8 x 96^2 crops, K = 65536."""
+    from vit_core.ssl.dino import DINOViT
+    from vit_core.ssl.dino.loss import DINOLoss
+    from vitssl_hip.optim import FusedAdamW
+    torch.manual_seed(0)
+    B, K = 8, 65536
+    model = DINOViT(num_blocks=12, input_shape=(3, 224, 224), embed_dim=768, patch_size=16, num_heads=12, mlp_dim=3072,
+                    dropout=0.0, output_dim=K, center_momentum=0.9).to(DEV).train()
+    views = [torch.rand(B, 3, 224, 224, device=DEV) for _ in range(2)] + [torch.rand(B, 3, 96, 96, device=DEV) for _ in range(8)]
+    crit = DINOLoss(0.04, 0.1)
+    opt = FusedAdamW(model.trainable_store(), lr=1e-4, weight_decay=1e-3)
+    c0 = model.center.clone()
+    loss = model.train_step(views, 2, crit, opt, None, teacher_momentum=0.996)
+    assert torch.isfinite(loss) and model.last_teacher.shape == (2 * B, K) and model.last_student.shape == (10 * B, K)
+    assert not torch.equal(model.center, c0)                                       # centre moved inside forward
+    # at init student == teacher and the centre starts at 0: teacher probs are a softmax
+    # over K=65536 logits, the loss is positive and bounded by log(K)/K-scaled terms
+    t = torch.softmax((model.last_teacher.view(2, B, K) - model.center) / 0.04, -1)
+    s = torch.log_softmax(model.last_student.view(10, B, K) / 0.1, -1)
+    want = -(t.sum(0) * s.sum(0)).sum() / (2 * B * K)                              # algebraic identity, torch on GPU as checker
+    assert abs(float(want) - float(loss)) < 2e-3 * abs(float(want))
+    loss2 = model.train_step(views, 2, crit, opt, None, teacher_momentum=0.996)
+    assert torch.isfinite(loss2)
