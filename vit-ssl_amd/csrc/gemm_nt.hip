@@ -25,9 +25,13 @@
 //         MFMAs of its neighbours, and the finer tiles fill the 256 CUs better when the
 //         256x256 grid is a poor multiple of 256 (e.g. N = 768: 588 tiles).
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 namespace {
+
+template <int V>
+using IC = std::integral_constant<int, V>;
 
 template <int BK_, int WM_, int WN_, int NBUF_ = 2>
 struct NtCfg {
@@ -62,6 +66,7 @@ struct NtParams {
   int tiles_m, tiles_n;
   int group_n;   // tile columns per raster group (their B panels stay L2-resident)
   int stagger;   // start-up delay units (x ~2.7 us) per phase group, 0 = off
+  int phases;    // MFMA clusters per K-step in the BIG loop: 2 or 4
 };
 
 // XOR applied to the 16-byte chunk index of tile row r (source side for the DMA, and on
@@ -72,7 +77,9 @@ __device__ __forceinline__ int nt_swz(int r) {
   return BK_ == 64 ? ((r >> 1) & 7) : 3 * ((r >> 3) & 1);
 }
 
-template <int BK_, int ROWS, int WAVES>
+// PART / NPARTS: issue only that share of this wave's DMA instructions (spreads the stage
+// of one tile over several MFMA clusters)
+template <int BK_, int ROWS, int WAVES, int PART = 0, int NPARTS = 1>
 __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, long long row0, int k0,
                                            int K, int wave, int lane) {
   constexpr int ROWB = BK_ * 2;
@@ -80,9 +87,11 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* ld
   constexpr int LPR = ROWB / 16;                // lanes per row
   constexpr int SLOTS = ROWS / RPI;
   static_assert(SLOTS % WAVES == 0, "tile rows must split evenly over the waves");
+  constexpr int PER = SLOTS / WAVES;
+  static_assert(PER % NPARTS == 0, "DMA instructions must split evenly over the parts");
 #pragma unroll
-  for (int j = 0; j < SLOTS / WAVES; ++j) {
-    const int i = wave * (SLOTS / WAVES) + j;   // wave-uniform instruction slot
+  for (int j = PART * (PER / NPARTS); j < (PART + 1) * (PER / NPARTS); ++j) {
+    const int i = wave * PER + j;               // wave-uniform instruction slot
     const int r = i * RPI + lane / LPR;         // tile row this lane fetches for
     const int c = lane % LPR;                   // 16-B chunk position in the LDS row
     const int sc = c ^ nt_swz<BK_>(r);          // chunk fetched from global
@@ -91,7 +100,7 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* ld
   }
 }
 
-template <int EPI, typename CFG>
+template <int EPI, typename CFG, int PH>
 __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt_kernel(NtParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK;
@@ -162,6 +171,46 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
     }
   };
 
+  auto compute_half = [&](const char* bufA, const char* bufB, auto kk_c) {
+    constexpr int kk = decltype(kk_c)::value;
+    const int coff = ((kk * 4 + kq) ^ swz) << 4;
+    bf16x8 fb[4], fa[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      fb[j] = *(const bf16x8*)(bufB + (wn * 64 + j * 16 + frag_row) * CFG::ROWB + coff);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      fa[i] = *(const bf16x8*)(bufA + (wm * 128 + i * 16 + frag_row) * CFG::ROWB + coff);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // 16-MFMA cluster: k-step kk, accumulator rows ih*4 .. ih*4+3
+  // (kk and ih are compile-time constants: a runtime index would push acc[] to scratch)
+  auto compute_quarter = [&](const char* bufA, const char* bufB, auto kk_c, auto ih_c) {
+    constexpr int kk = decltype(kk_c)::value, ih = decltype(ih_c)::value;
+    const int coff = ((kk * 4 + kq) ^ swz) << 4;
+    bf16x8 fb[4], fa[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      fb[j] = *(const bf16x8*)(bufB + (wn * 64 + j * 16 + frag_row) * CFG::ROWB + coff);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      fa[i] = *(const bf16x8*)(bufA + (wm * 128 + (ih * 4 + i) * 16 + frag_row) * CFG::ROWB + coff);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        acc[j][ih * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[j][ih * 4 + i], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
   if constexpr (CFG::NBUF == 2) {
     stage_tile<BK, BM, CFG::WAVES>(rsA, smem, m0, 0, p.K, wave, lane);
     stage_tile<BK, BN, CFG::WAVES>(rsB, smem + CFG::A_BYTES, n0, 0, p.K, wave, lane);
@@ -169,12 +218,33 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
     __syncthreads();
     for (int t = 0; t < nk; ++t) {
       char* bufA = smem + (t & 1) * CFG::BUF_BYTES;
-      if (t + 1 < nk) {
-        char* nA = smem + ((t + 1) & 1) * CFG::BUF_BYTES;
-        stage_tile<BK, BM, CFG::WAVES>(rsA, nA, m0, (t + 1) * BK, p.K, wave, lane);
-        stage_tile<BK, BN, CFG::WAVES>(rsB, nA + CFG::A_BYTES, n0, (t + 1) * BK, p.K, wave, lane);
+      char* nA = smem + ((t + 1) & 1) * CFG::BUF_BYTES;
+      const bool more = t + 1 < nk;
+      if constexpr (BK == 64) {
+        // spread the next tile's DMA over the step: A before the first MFMA block, B between
+        // the two blocks (a single 64-KiB burst right after the barrier queues in the TA)
+        if constexpr (PH == 4) {
+          if (more) stage_tile<BK, BM, CFG::WAVES, 0, 2>(rsA, nA, m0, (t + 1) * BK, p.K, wave, lane);
+          compute_quarter(bufA, bufA + CFG::A_BYTES, IC<0>{}, IC<0>{});
+          if (more) stage_tile<BK, BM, CFG::WAVES, 1, 2>(rsA, nA, m0, (t + 1) * BK, p.K, wave, lane);
+          compute_quarter(bufA, bufA + CFG::A_BYTES, IC<0>{}, IC<1>{});
+          if (more) stage_tile<BK, BN, CFG::WAVES, 0, 2>(rsB, nA + CFG::A_BYTES, n0, (t + 1) * BK, p.K, wave, lane);
+          compute_quarter(bufA, bufA + CFG::A_BYTES, IC<1>{}, IC<0>{});
+          if (more) stage_tile<BK, BN, CFG::WAVES, 1, 2>(rsB, nA + CFG::A_BYTES, n0, (t + 1) * BK, p.K, wave, lane);
+          compute_quarter(bufA, bufA + CFG::A_BYTES, IC<1>{}, IC<1>{});
+        } else {
+          if (more) stage_tile<BK, BM, CFG::WAVES>(rsA, nA, m0, (t + 1) * BK, p.K, wave, lane);
+          compute_half(bufA, bufA + CFG::A_BYTES, IC<0>{});
+          if (more) stage_tile<BK, BN, CFG::WAVES>(rsB, nA + CFG::A_BYTES, n0, (t + 1) * BK, p.K, wave, lane);
+          compute_half(bufA, bufA + CFG::A_BYTES, IC<1>{});
+        }
+      } else {
+        if (more) {
+          stage_tile<BK, BM, CFG::WAVES>(rsA, nA, m0, (t + 1) * BK, p.K, wave, lane);
+          stage_tile<BK, BN, CFG::WAVES>(rsB, nA + CFG::A_BYTES, n0, (t + 1) * BK, p.K, wave, lane);
+        }
+        compute_stage(bufA, bufA + CFG::A_BYTES);
       }
-      compute_stage(bufA, bufA + CFG::A_BYTES);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
@@ -344,11 +414,11 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
   }
 }
 
-template <int EPI, typename CFG>
+template <int EPI, typename CFG, int PH = 2>
 int launch_cfg(NtParams p, hipStream_t s) {
   static bool attr_done = false;  // idempotent; a benign race sets the same value
   if (!attr_done && CFG::LDS_BYTES > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, CFG>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, CFG, PH>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        CFG::LDS_BYTES);
     if (e != hipSuccess) {
       vitssl_set_error("gemm_nt: cannot raise dynamic LDS to %d: %s", CFG::LDS_BYTES, hipGetErrorString(e));
@@ -374,8 +444,9 @@ int launch_cfg(NtParams p, hipStream_t s) {
     const bool heavy = EPI == VITSSL_EPI_GELU || EPI == VITSSL_EPI_DGELU || EPI == VITSSL_EPI_RESID || EPI == VITSSL_EPI_F32;
     const int nk = p.K / CFG::BK;
     p.stagger = (knob && heavy && p.tiles_m * p.tiles_n > 256) ? (nk * knob + 5) / 6 : 0;
+    p.phases = PH;
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<EPI, CFG>), dim3(p.tiles_m * p.tiles_n), dim3(CFG::THREADS), CFG::LDS_BYTES, s, p);
+  hipLaunchKernelGGL((gemm_nt_kernel<EPI, CFG, PH>), dim3(p.tiles_m * p.tiles_n), dim3(CFG::THREADS), CFG::LDS_BYTES, s, p);
   VS_CHECK_LAUNCH("gemm_nt");
   return VITSSL_OK;
 }
@@ -408,7 +479,13 @@ int launch_nt(const NtParams& p, hipStream_t s) {
     small = big_tiles < 64;
   }
   if (mode == 3) return launch_cfg<EPI, NtDeep>(p, s);
-  return small ? launch_cfg<EPI, NtSmall>(p, s) : launch_cfg<EPI, NtBig>(p, s);
+  if (small) return launch_cfg<EPI, NtSmall>(p, s);
+  static int ph = -1;   // MFMA clusters per K-step in the BIG loop (VITSSL_NT_PHASES, developer knob)
+  if (ph < 0) {
+    const char* e = getenv("VITSSL_NT_PHASES");
+    ph = e ? atoi(e) : 2;
+  }
+  return ph == 4 ? launch_cfg<EPI, NtBig, 4>(p, s) : launch_cfg<EPI, NtBig, 2>(p, s);
 }
 
 }  // namespace
