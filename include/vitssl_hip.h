@@ -79,9 +79,9 @@ int vitssl_grad_mask_cast(const float* g, void* gm_bf16, float* gm_colsum, vitss
 enum {
   VITSSL_EPI_BF16 = 0,         /* out0(bf16) = acc + bias                                         */
   VITSSL_EPI_F32 = 1,          /* out0(f32)  = acc + bias                                         */
-  VITSSL_EPI_GELU = 2,         /* out0(bf16) = u = acc + bias ; out1(bf16) = drop(gelu_erf(u))    */
+  VITSSL_EPI_GELU = 2,         /* u = bf16(acc+bias); out1(bf16) = keep*s*gelu_erf(u); out0(bf16) = g' = keep*s*gelu_erf'(u) */
   VITSSL_EPI_RESID = 3,        /* out0(f32)  = aux(f32 [M,N]) + drop(acc + bias)                  */
-  VITSSL_EPI_DGELU = 4,        /* out0(bf16) = acc * dropmask * gelu'(aux(bf16 u [M,N]))          */
+  VITSSL_EPI_DGELU = 4,        /* out0(bf16) = acc * aux(bf16 g' [M,N] saved by EPI_GELU)         */
   VITSSL_EPI_EMBED = 5         /* patch-embedding epilogue, see vitssl_embed_t                    */
 };
 

@@ -43,6 +43,27 @@ __device__ __forceinline__ void load_tile(char* lds, const bf16_t* g, long long 
   }
 }
 
+// asynchronous version: LDS-DMA (buffer_load ... lds), 1 KiB = 8 tile rows per wave
+// instruction, the swizzle applied on the SOURCE chunk (same involution as tile_off);
+// rows >= N fall outside the buffer descriptor and are zero-filled by the hardware.
+// Completion = this wave's vmcnt, then a workgroup barrier.  Np/8 instructions in total,
+// spread over NWAVES waves; returns how many this wave issued.
+template <int NWAVES>
+__device__ __forceinline__ int dma_tile(char* lds, const bf16_t* g, long long stride, int N, int Np, int wave, int lane) {
+  const unsigned bytes = (unsigned)((long long)(N - 1) * stride * 2 + ROWB);
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)g, 0, (int)bytes, 0x00020000);
+  int n = 0;
+  for (int i = wave; i < Np / 8; i += NWAVES) {
+    const int row = i * 8 + (lane >> 3);
+    const int c = lane & 7;
+    const int sc = c ^ (((row >> 1) & 3) << 1);
+    const unsigned voff = (unsigned)((long long)row * stride * 2 + sc * 16);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds + i * 1024), 16, voff, 0, 0, 0);
+    ++n;
+  }
+  return n;
+}
+
 // natural fragment (8 consecutive d) of row `row`, k-step kk, from an LDS tile
 __device__ __forceinline__ bf16x8 lds_frag(const char* tile, int row, int kk, int lane) {
   return *(const bf16x8*)(tile + tile_off(row, 4 * kk + (lane >> 4)));
@@ -123,23 +144,44 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
   const bf16_t* qg = qkv + (long long)b * N * stride + h * DH;
   const bf16_t* kg = qg + (long long)H * DH;
   const bf16_t* vg = kg + (long long)H * DH;
-  load_tile(Kt, kg, stride, N, Np, threadIdx.x, 256);
-  load_tile(Vt, vg, stride, N, Np, threadIdx.x, 256);
-  __syncthreads();
-
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, li = lane & 15;
   const float scale = 0.125f;  // 1/sqrt(64)
   const int nqp = (N + 31) >> 5;   // pairs of 16-query tiles
 
-  for (int qp = wave; qp < nqp; qp += 4) {
+  // Q fragments of this wave's first pair (ordinary loads) and the K tile (LDS-DMA) are
+  // awaited together; the V tile's DMA is issued only then, so it lands underneath the
+  // first S = K.Q^T + softmax.  (No ordinary-load result is consumed while a DMA is in
+  // flight: hipcc would answer with a full vmcnt(0) drain.)
+  bf16x8 qn[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    qn[t][0] = glb_frag(qg, stride, wave * 32 + t * 16 + li, 0, N, lane);
+    qn[t][1] = glb_frag(qg, stride, wave * 32 + t * 16 + li, 1, N, lane);
+  }
+  dma_tile<4>(Kt, kg, stride, N, Np, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  dma_tile<4>(Vt, vg, stride, N, Np, wave, lane);
+
+  const int iters = (nqp + 3) >> 2;   // same trip count for every wave (uniform barriers)
+  for (int it = 0; it < iters; ++it) {
+    const int qp = wave + 4 * it;
+    const bool active = qp < nqp;      // wave-uniform
     const int q[2] = {qp * 32 + li, qp * 32 + 16 + li};
     bf16x8 qf[2][2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      qf[t][0] = glb_frag(qg, stride, q[t], 0, N, lane);
-      qf[t][1] = glb_frag(qg, stride, q[t], 1, N, lane);
+      qf[t][0] = qn[t][0];
+      qf[t][1] = qn[t][1];
+    }
+    if (it + 1 < iters) {              // software prefetch of the next pair's Q fragments
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        qn[t][0] = glb_frag(qg, stride, q[t] + 128, 0, N, lane);
+        qn[t][1] = glb_frag(qg, stride, q[t] + 128, 1, N, lane);
+      }
     }
     f32x4 s0[NKT], s1[NKT];
 #pragma unroll
@@ -174,6 +216,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
       }
     }
     // O^T[d][q] = sum_key V[key][d] P[q][key]
+    if (it == 0) {   // uniform: every wave's share of the V tile has landed
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    if (!active) continue;
     f32x4 o0[4], o1[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
@@ -224,13 +271,17 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16_t* __restr
   const bf16_t* kg = qg + (long long)H * DH;
   const bf16_t* vg = kg + (long long)H * DH;
   const bf16_t* dog = dout + (long long)b * N * (H * DH) + h * DH;
-  load_tile(Qt, qg, stride, N, Np, threadIdx.x, 512);
-  load_tile(Dt, dog, (long long)H * DH, N, Np, threadIdx.x, 512);
+  {
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    dma_tile<8>(Qt, qg, stride, N, Np, wv, threadIdx.x & 63);
+    dma_tile<8>(Dt, dog, (long long)H * DH, N, Np, wv, threadIdx.x & 63);
+  }
   for (int i = threadIdx.x; i < Np; i += 512) {
     // padded queries: lse = +inf makes p = exp(0 - inf) = 0
     lse_s[i] = i < N ? lse[((long long)b * H + h) * N + i] : INFINITY;
     del_s[i] = i < N ? delta[((long long)b * H + h) * N + i] : 0.f;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
@@ -328,15 +379,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
   const bf16_t* vg = kg + (long long)H * DH;
   const bf16_t* dog = dout + (long long)b * N * (H * DH) + h * DH;
   const bf16_t* og = outp + (long long)b * N * (H * DH) + h * DH;
-  load_tile(Kt, kg, stride, N, Np, threadIdx.x, 256);
-  load_tile(Vt, vg, stride, N, Np, threadIdx.x, 256);
-  __syncthreads();
-
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, li = lane & 15;
   const float scale = 0.125f;
   const int nqp = (N + 31) >> 5;
+  dma_tile<4>(Kt, kg, stride, N, Np, wave, lane);
+  dma_tile<4>(Vt, vg, stride, N, Np, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
 
   for (int qp = wave; qp < nqp; qp += 4) {
     const int q[2] = {qp * 32 + li, qp * 32 + 16 + li};

@@ -133,6 +133,22 @@ __device__ __forceinline__ float erf_as(float x) {
   return copysignf(r, x);
 }
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
+// gelu(x) and gelu'(x) = Phi(x) + x phi(x) together: the exp(-x^2/2) inside the erf
+// approximation is exactly the Gaussian factor of phi(x).
+__device__ __forceinline__ void gelu_both(float x, float& y, float& dy) {
+  const float ax = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  poly *= t;
+  const float e = __expf(-ax * ax);                 // = exp(-x^2/2)
+  const float erfv = copysignf(fmaf(-poly, e, 1.0f), x);
+  const float cdf = 0.5f * (1.0f + erfv);
+  y = x * cdf;
+  dy = fmaf(x * 0.3989422804014327f, e, cdf);
+}
 // d/dx gelu(x) = Phi(x) + x * phi(x)
 __device__ __forceinline__ float dgelu_f(float x) {
   const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752f));

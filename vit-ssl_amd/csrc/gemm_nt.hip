@@ -334,30 +334,36 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
         const u32x2 w1 = {pack_bf2(v[1][0], v[1][1]), pack_bf2(v[1][2], v[1][3])};
         store_bf16_pair((bf16_t*)p.out0, m, jp, w0, w1, okA, okB, okm);
       } else if constexpr (EPI == VITSSL_EPI_GELU) {
-        u32x2 w[2], a[2];
+        // u = bf16(acc + bias) (never stored); out1 = a = keep*scale*gelu(u) feeds the next
+        // GEMM; out0 = g' = keep*scale*gelu'(u) is what the backward dGELU epilogue needs.
+        u32x2 gp[2], a[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          w[h] = u32x2{pack_bf2(v[h][0], v[h][1]), pack_bf2(v[h][2], v[h][3])};
           float mult[4] = {1.f, 1.f, 1.f, 1.f};
           if (p.drop_on) drop_mult4(p.dk, (unsigned long long)(m * p.N + nn[h]) >> 2, mult);
-          const float g0 = gelu_f(bf_lo(w[h][0])) * mult[0], g1 = gelu_f(bf_hi(w[h][0])) * mult[1];
-          const float g2 = gelu_f(bf_lo(w[h][1])) * mult[2], g3 = gelu_f(bf_hi(w[h][1])) * mult[3];
-          a[h] = u32x2{pack_bf2(g0, g1), pack_bf2(g2, g3)};
+          float y[4], d[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            gelu_both(round_bf(v[h][r]), y[r], d[r]);
+            y[r] *= mult[r];
+            d[r] *= mult[r];
+          }
+          a[h] = u32x2{pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
+          gp[h] = u32x2{pack_bf2(d[0], d[1]), pack_bf2(d[2], d[3])};
         }
-        store_bf16_pair((bf16_t*)p.out0, m, jp, w[0], w[1], okA, okB, okm);
+        store_bf16_pair((bf16_t*)p.out0, m, jp, gp[0], gp[1], okA, okB, okm);
         store_bf16_pair((bf16_t*)p.out1, m, jp, a[0], a[1], okA, okB, okm);
       } else if constexpr (EPI == VITSSL_EPI_DGELU) {
+        // du = acc * g'  (g' already carries the dropout mask and its scale)
         u32x2 w[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          u32x2 u = {0u, 0u};
-          if (okm && okn[h]) u = *(const u32x2*)((const bf16_t*)p.aux + m * p.N + nn[h]);
-          float mult[4] = {1.f, 1.f, 1.f, 1.f};
-          if (p.drop_on) drop_mult4(p.dk, (unsigned long long)(m * p.N + nn[h]) >> 2, mult);
-          v[h][0] *= mult[0] * dgelu_f(bf_lo(u[0]));
-          v[h][1] *= mult[1] * dgelu_f(bf_hi(u[0]));
-          v[h][2] *= mult[2] * dgelu_f(bf_lo(u[1]));
-          v[h][3] *= mult[3] * dgelu_f(bf_hi(u[1]));
+          u32x2 gpv = {0u, 0u};
+          if (okm && okn[h]) gpv = *(const u32x2*)((const bf16_t*)p.aux + m * p.N + nn[h]);
+          v[h][0] *= bf_lo(gpv[0]);
+          v[h][1] *= bf_hi(gpv[0]);
+          v[h][2] *= bf_lo(gpv[1]);
+          v[h][3] *= bf_hi(gpv[1]);
           w[h] = u32x2{pack_bf2(v[h][0], v[h][1]), pack_bf2(v[h][2], v[h][3])};
         }
         store_bf16_pair((bf16_t*)p.out0, m, jp, w[0], w[1], okA, okB, okm);

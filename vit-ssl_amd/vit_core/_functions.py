@@ -202,7 +202,7 @@ class _FFNFn(Function):
         ops.grad_mask_cast(dy2, dyb, db2)
         du = _empty((rows, Fd), BF16, dy2)
         db1 = torch.zeros(Fd, dtype=F32, device=dy2.device)
-        ops.gemm_nt(dyb, w2t, du, L.EPI_DGELU, aux=u, colsum=db1, drop=drop)
+        ops.gemm_nt(dyb, w2t, du, L.EPI_DGELU, aux=u, colsum=db1)   # u holds g' (mask and scale folded in)
         dw2 = torch.zeros(D, Fd, dtype=F32, device=dy2.device)
         ops.gemm_tn(dyb, a, dw2)
         dx = _empty((rows, D), F32, dy2)

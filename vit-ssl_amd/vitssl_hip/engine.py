@@ -340,7 +340,7 @@ class EncoderStack:
             a_ = self.bp[i] + "self_attention."
             # MLP
             ops.gemm_nt(gm, st.w(self._n(i, "w2") + ".T"), du, L.EPI_DGELU, aux=s["u"],
-                        colsum=gv(self._n(i, "feed_forward.linear_in.bias")), drop=self._drop(i, 1, seed, training))
+                        colsum=gv(self._n(i, "feed_forward.linear_in.bias")))   # s["u"] holds g' = keep*scale*gelu'(u)
             ops.gemm_tn(gm, s["a"], gv(self._n(i, "feed_forward.linear_out.weight"), (D, F)))
             ops.gemm_nt(du, st.w(self._n(i, "w1") + ".T"), dh_, L.EPI_BF16)
             ops.gemm_tn(du, s["h2"], gv(self._n(i, "feed_forward.linear_in.weight"), (F, D)))
