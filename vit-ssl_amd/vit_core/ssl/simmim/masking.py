@@ -7,6 +7,7 @@ index bookkeeping, 1 KiB per image) and only the resulting mask / index lists ar
 uploaded; the tensor work (mask-token substitution, target gather) runs in HIP."""
 from typing import Tuple
 
+import numpy as np
 import torch
 
 
@@ -19,13 +20,21 @@ def draw_mask(batch_size: int, num_patches: int, mask_ratio: float, generator=No
     return mask
 
 
+def mask_indices_np(mask: torch.Tensor):
+    """NumPy version (single-threaded on purpose: torch CPU ops on 50k-element tensors fan
+    out to every core via OpenMP, and the spinning workers starve the HIP runtime's
+    signal-handling thread -- measured 7 ms of GPU idle per step on a 256-core host)."""
+    flat = mask.numpy().reshape(-1)
+    idx = np.flatnonzero(flat).astype(np.int32)
+    inv = np.cumsum(flat, dtype=np.int32) - 1
+    inv[~flat] = -1
+    return idx, inv, flat.view(np.uint8)
+
+
 def mask_indices(mask: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """(idx int32 [n_masked] ascending flat (b, n) rows, inv int32 [B*N]: compact row or -1)."""
-    flat = mask.reshape(-1)
-    idx = flat.nonzero(as_tuple=False).squeeze(1).to(torch.int32)
-    inv = torch.cumsum(flat.to(torch.int32), 0, dtype=torch.int32) - 1
-    inv = torch.where(flat, inv, torch.full_like(inv, -1))
-    return idx, inv
+    idx, inv, _ = mask_indices_np(mask.contiguous())
+    return torch.from_numpy(idx), torch.from_numpy(inv)
 
 
 def simple_masking(patches: torch.Tensor, mask_ratio: float):

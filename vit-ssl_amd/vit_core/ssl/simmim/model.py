@@ -20,7 +20,7 @@ from torch.autograd import Function
 from ... import _runtime as R
 from ..._runtime import BF16, F32, L, ops
 from ...encoder_block import EncoderBlock
-from .masking import draw_mask, mask_indices
+from .masking import draw_mask, mask_indices_np
 
 
 class _SimMIMRuntime:
@@ -61,7 +61,42 @@ class _SimMIMRuntime:
                            st.view("positional_embedding", (self.N, self.D)), self.N, self.N, 0))
         return x0, patches
 
-    def forward(self, x, training: bool, save: bool, mask_cpu=None):
+    def prepare_mask(self, mask_cpu, dev):
+        """Host mask -> (idx, inv, mask_u8) device tensors.
+
+        Staging goes through a small RING of persistent pinned host buffers (one
+        hipHostMalloc per shape, ever): pinning fresh pages every step (`.pin_memory()`)
+        costs milliseconds and serialises with the launch queue on ROCm -- measured 15 ms
+        of GPU idle per step.  A slot is reused only after the event recorded behind its
+        last host-to-device copies has completed."""
+        idx, inv, mflat = mask_indices_np(mask_cpu.contiguous())
+        M, Mm = inv.size, idx.size
+        key = (M, Mm, str(dev))
+        if getattr(self, "_stage_key", None) != key:
+            nslots = 4
+            self._stage = [dict(idx=torch.empty(Mm, dtype=torch.int32).pin_memory(),
+                                inv=torch.empty(M, dtype=torch.int32).pin_memory(),
+                                mask=torch.empty(M, dtype=torch.uint8).pin_memory(), ev=None) for _ in range(nslots)]
+            self._stage_dev = [dict(idx=torch.empty(Mm, dtype=torch.int32, device=dev),
+                                    inv=torch.empty(M, dtype=torch.int32, device=dev),
+                                    mask=torch.empty(M, dtype=torch.uint8, device=dev)) for _ in range(nslots)]
+            self._stage_pos = 0
+            self._stage_key = key
+        k = self._stage_pos % len(self._stage)
+        self._stage_pos += 1
+        slot, d = self._stage[k], self._stage_dev[k]
+        if slot["ev"] is not None:
+            slot["ev"].synchronize()
+        slot["idx"].numpy()[:] = idx          # plain memcpy into the pinned pages (no torch CPU op)
+        slot["inv"].numpy()[:] = inv
+        slot["mask"].numpy()[:] = mflat
+        for name in ("idx", "inv", "mask"):
+            d[name].copy_(slot[name], non_blocking=True)
+        slot["ev"] = torch.cuda.Event()
+        slot["ev"].record(torch.cuda.current_stream())
+        return d["idx"], d["inv"], d["mask"]
+
+    def forward(self, x, training: bool, save: bool, mask_cpu=None, prepared=None):
         st, ws = self.store, self.ws
         if x.dim() != 4 or tuple(x.shape[1:]) != (self.C, self.H, self.W):
             raise L.VitsslError(f"SimMIMViT: expected input [B,{self.C},{self.H},{self.W}], got {tuple(x.shape)}")
@@ -69,15 +104,14 @@ class _SimMIMRuntime:
         B = x.shape[0]
         M = B * self.N
         st.refresh_weights()
-        if mask_cpu is None:
-            mask_cpu = draw_mask(B, self.N, self.model.mask_ratio)          # host RNG first (reference order)
-        seed = R.next_seed() if (training and self.stack.p > 0) else 0
-        idx, inv = mask_indices(mask_cpu)
-        Mm = idx.numel()
         dev = x.device
-        idx_d = idx.pin_memory().to(dev, non_blocking=True)
-        inv_d = inv.pin_memory().to(dev, non_blocking=True)
-        mask_d = mask_cpu.reshape(-1).to(torch.uint8).pin_memory().to(dev, non_blocking=True)
+        if prepared is None:
+            if mask_cpu is None:
+                mask_cpu = draw_mask(B, self.N, self.model.mask_ratio)      # host RNG first (reference order)
+            prepared = self.prepare_mask(mask_cpu, dev)
+        seed = R.next_seed() if (training and self.stack.p > 0) else 0
+        idx_d, inv_d, mask_d = prepared
+        Mm = idx_d.numel()
 
         targets = torch.empty(Mm, self.Pd, dtype=F32, device=dev)
         ops.gather_patches_f32(x, idx_d, targets, self.P)
@@ -208,7 +242,7 @@ class SimMIMViT(nn.Module):
         return feats.clone() if return_patch_features else feats.mean(dim=1)
 
     # ------------------------------------------------------------------ fused step
-    def train_step(self, x: torch.Tensor, optimizer, reducer=None, mask_cpu=None) -> torch.Tensor:
+    def train_step(self, x: torch.Tensor, optimizer, reducer=None, mask_cpu=None, prepared=None) -> torch.Tensor:
         """One full optimisation step (zero_grad -> forward -> L1(mean) -> backward ->
         gradient all-reduce -> AdamW) with no autograd graph; returns the loss as a
         device scalar (no host sync).  Equivalent to utils/trainers/simmim_trainer.py:61-76
@@ -223,7 +257,7 @@ class SimMIMViT(nn.Module):
             st.gflat.zero_()
             if reducer is not None:
                 reducer.begin()
-            pred, targets, _ = rt.forward(x, True, save=True, mask_cpu=mask_cpu)
+            pred, targets, _ = rt.forward(x, True, save=True, mask_cpu=mask_cpu, prepared=prepared)
             n = pred.numel()
             loss_sum = rt.ws.get("loss_sum", (1,), F32, x.device)
             loss_sum.zero_()
