@@ -67,6 +67,7 @@ struct NtParams {
   int group_n;   // tile columns per raster group (their B panels stay L2-resident)
   int stagger;   // start-up delay units (x ~2.7 us) per phase group, 0 = off
   int phases;    // MFMA clusters per K-step in the BIG loop: 2 or 4
+  int l2_prefetch;
 };
 
 // XOR applied to the 16-byte chunk index of tile row r (source side for the DMA, and on
@@ -81,7 +82,7 @@ __device__ __forceinline__ int nt_swz(int r) {
 // of one tile over several MFMA clusters)
 template <int BK_, int ROWS, int WAVES, int PART = 0, int NPARTS = 1>
 __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, long long row0, int k0,
-                                           int K, int wave, int lane) {
+                                           int K, int wave, int lane, const bf16_t* gbase = nullptr, long long nrows = 0) {
   constexpr int ROWB = BK_ * 2;
   constexpr int RPI = 1024 / ROWB;              // tile rows per 1-KiB wave-instruction
   constexpr int LPR = ROWB / 16;                // lanes per row
@@ -95,6 +96,33 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* ld
     const int r = i * RPI + lane / LPR;         // tile row this lane fetches for
     const int c = lane % LPR;                   // 16-B chunk position in the LDS row
     const int sc = c ^ nt_swz<BK_>(r);          // chunk fetched from global
+#ifdef VS_NT_GLOBAL_LDS
+    long long gr = row0 + r;
+    if (gr > nrows - 1) gr = nrows - 1;   // clamp: duplicated rows only feed outputs that are never stored
+    const char* gp = (const char*)gbase + (gr * (long long)K + k0) * 2 + sc * 16;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp, LDS_PTR(lds_tile + i * 1024), 16, 0, 0);
+#else
+    const unsigned voff = (unsigned)(((row0 + r) * (long long)K + k0) * 2 + sc * 16);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + i * 1024), 16, voff, 0, 0, 0);
+#endif
+  }
+}
+
+// Half-tile staging for the split-half pipeline (BK = 64, 8 waves, 256-row tiles).  A
+// tile row belongs to the LO half when (row % PERIOD) < PERIOD/2 -- PERIOD = 128 for the A
+// tile (per-wave m-reps 0..3), 64 for the B tile (per-wave n-reps 0..1).  Each half is 16
+// one-KiB DMA instructions = 2 per wave.
+template <int PERIOD, int HI>
+__device__ __forceinline__ void stage_half(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, long long row0, int k0,
+                                           int K, int wave, int lane) {
+  constexpr int SPP = PERIOD / 8;               // instruction slots per period
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int h = wave * 2 + j;                 // 0..15: index inside this half
+    const int i = (h / (SPP / 2)) * SPP + HI * (SPP / 2) + (h % (SPP / 2));   // slot (8 rows each)
+    const int r = i * 8 + (lane >> 3);
+    const int c = lane & 7;
+    const int sc = c ^ ((r >> 1) & 7);
     const unsigned voff = (unsigned)(((row0 + r) * (long long)K + k0) * 2 + sc * 16);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + i * 1024), 16, voff, 0, 0, 0);
   }
@@ -211,15 +239,109 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
     __builtin_amdgcn_s_setprio(0);
   };
 
-  if constexpr (CFG::NBUF == 2) {
-    stage_tile<BK, BM, CFG::WAVES>(rsA, smem, m0, 0, p.K, wave, lane);
-    stage_tile<BK, BN, CFG::WAVES>(rsB, smem + CFG::A_BYTES, n0, 0, p.K, wave, lane);
+  if constexpr (CFG::NBUF == 2 && PH == 3 && BK == 64 && CFG::WAVES == 8) {
+    // ---- split-half pipeline ------------------------------------------------------
+    // step t:  [B0] issue LO(t+1) | Q_ll(t) | vmcnt(4): HI(t) landed [B1] issue HI(t+1) |
+    //          Q_lh, Q_hl, Q_hh(t) | vmcnt(4): LO(t+1) landed [B0 of t+1] ...
+    // Each half has a full step to land and the DMA queue never drains to zero.
+    auto frA = [&](const char* bufA, int kk, int i) {
+      return *(const bf16x8*)(bufA + (wm * 128 + i * 16 + frag_row) * CFG::ROWB + (((kk * 4 + kq) ^ swz) << 4));
+    };
+    auto frB = [&](const char* bufB, int kk, int j) {
+      return *(const bf16x8*)(bufB + (wn * 64 + j * 16 + frag_row) * CFG::ROWB + (((kk * 4 + kq) ^ swz) << 4));
+    };
+    // prologue: tile 0 (both halves), wait, then LO(1) is issued inside step 0
+    stage_half<128, 0>(rsA, smem, m0, 0, p.K, wave, lane);
+    stage_half<64, 0>(rsB, smem + CFG::A_BYTES, n0, 0, p.K, wave, lane);
+    stage_half<128, 1>(rsA, smem, m0, 0, p.K, wave, lane);
+    stage_half<64, 1>(rsB, smem + CFG::A_BYTES, n0, 0, p.K, wave, lane);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // LO(0) landed
+    __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < nk; ++t) {
+      const char* bufA = smem + (t & 1) * CFG::BUF_BYTES;
+      const char* bufB = bufA + CFG::A_BYTES;
+      char* nA = smem + ((t + 1) & 1) * CFG::BUF_BYTES;
+      const bool more = t + 1 < nk;
+      if (more) {
+        stage_half<128, 0>(rsA, nA, m0, (t + 1) * BK, p.K, wave, lane);
+        stage_half<64, 0>(rsB, nA + CFG::A_BYTES, n0, (t + 1) * BK, p.K, wave, lane);
+      }
+      bf16x8 alo[2][4], blo[2][2];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) blo[kk][j] = frB(bufB, kk, j);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) alo[kk][i] = frA(bufA, kk, i);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blo[kk][j], alo[kk][i], acc[j][i], 0, 0, 0);
+      // HI(t) must have landed (every wave's share): allow only the LO(t+1) DMAs in flight
+      if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (more) {
+        stage_half<128, 1>(rsA, nA, m0, (t + 1) * BK, p.K, wave, lane);
+        stage_half<64, 1>(rsB, nA + CFG::A_BYTES, n0, (t + 1) * BK, p.K, wave, lane);
+      }
+      bf16x8 bhi[2][2];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bhi[kk][j] = frB(bufB, kk, 2 + j);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            acc[2 + j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi[kk][j], alo[kk][i], acc[2 + j][i], 0, 0, 0);
+      bf16x8 ahi[2][4];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ahi[kk][i] = frA(bufA, kk, 4 + i);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            acc[j][4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blo[kk][j], ahi[kk][i], acc[j][4 + i], 0, 0, 0);
+            acc[2 + j][4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi[kk][j], ahi[kk][i], acc[2 + j][4 + i], 0, 0, 0);
+          }
+      // LO(t+1) must have landed before the next step reads it; HI(t+1) may stay in flight
+      if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  } else if constexpr (CFG::NBUF == 2) {
+    stage_tile<BK, BM, CFG::WAVES>(rsA, smem, m0, 0, p.K, wave, lane, p.A, p.M);
+    stage_tile<BK, BN, CFG::WAVES>(rsB, smem + CFG::A_BYTES, n0, 0, p.K, wave, lane, p.B, p.N);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int t = 0; t < nk; ++t) {
       char* bufA = smem + (t & 1) * CFG::BUF_BYTES;
       char* nA = smem + ((t + 1) & 1) * CFG::BUF_BYTES;
       const bool more = t + 1 < nk;
+      if constexpr (BK == 64 && CFG::WAVES == 8) {
+        // L2 warm-up of the streamed A panel two K-steps ahead: one throw-away dword per
+        // 64-byte segment (256 rows x 2 segments = 512 threads).  The first workgroup to
+        // touch a line pays the HBM latency here instead of in the LDS-DMA of step t+1.
+        // (asm: the result register is never read; the load is retired by the manual
+        // vmcnt(0) at the end of this step.)
+        if (p.l2_prefetch && t + 2 < nk) {
+          const unsigned poff = (unsigned)(((m0 + (threadIdx.x >> 1)) * (long long)p.K + (t + 2) * BK) * 2 + (threadIdx.x & 1) * 64);
+          unsigned dummy;
+          asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(dummy) : "v"(poff), "s"(rsA) : "memory");
+        }
+      }
       if constexpr (BK == 64) {
         // spread the next tile's DMA over the step: A before the first MFMA block, B between
         // the two blocks (a single 64-KiB burst right after the barrier queues in the TA)
@@ -233,9 +355,9 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
           if (more) stage_tile<BK, BN, CFG::WAVES, 1, 2>(rsB, nA + CFG::A_BYTES, n0, (t + 1) * BK, p.K, wave, lane);
           compute_quarter(bufA, bufA + CFG::A_BYTES, IC<1>{}, IC<1>{});
         } else {
-          if (more) stage_tile<BK, BM, CFG::WAVES>(rsA, nA, m0, (t + 1) * BK, p.K, wave, lane);
+          if (more) stage_tile<BK, BM, CFG::WAVES>(rsA, nA, m0, (t + 1) * BK, p.K, wave, lane, p.A, p.M);
           compute_half(bufA, bufA + CFG::A_BYTES, IC<0>{});
-          if (more) stage_tile<BK, BN, CFG::WAVES>(rsB, nA + CFG::A_BYTES, n0, (t + 1) * BK, p.K, wave, lane);
+          if (more) stage_tile<BK, BN, CFG::WAVES>(rsB, nA + CFG::A_BYTES, n0, (t + 1) * BK, p.K, wave, lane, p.B, p.N);
           compute_half(bufA, bufA + CFG::A_BYTES, IC<1>{});
         }
       } else {
@@ -451,6 +573,12 @@ int launch_cfg(NtParams p, hipStream_t s) {
     const int nk = p.K / CFG::BK;
     p.stagger = (knob && heavy && p.tiles_m * p.tiles_n > 256) ? (nk * knob + 5) / 6 : 0;
     p.phases = PH;
+    static int pf = -1;
+    if (pf < 0) {
+      const char* e = getenv("VITSSL_NT_L2PF");
+      pf = e ? atoi(e) : 0;
+    }
+    p.l2_prefetch = pf;
   }
   hipLaunchKernelGGL((gemm_nt_kernel<EPI, CFG, PH>), dim3(p.tiles_m * p.tiles_n), dim3(CFG::THREADS), CFG::LDS_BYTES, s, p);
   VS_CHECK_LAUNCH("gemm_nt");
@@ -491,6 +619,7 @@ int launch_nt(const NtParams& p, hipStream_t s) {
     const char* e = getenv("VITSSL_NT_PHASES");
     ph = e ? atoi(e) : 2;
   }
+  if (ph == 3) return launch_cfg<EPI, NtBig, 3>(p, s);
   return ph == 4 ? launch_cfg<EPI, NtBig, 4>(p, s) : launch_cfg<EPI, NtBig, 2>(p, s);
 }
 
