@@ -43,6 +43,23 @@ def train_flops_per_image(D, L, H, F, N, Pd, nm):
     return 3 * (blocks + head) + 2 * proj
 
 
+def pmc_traffic_per_launch(family="gemm_nt"):
+    """HBM bytes per launch of the dominant kernel family from the committed rocprofv3 PMC
+    passes (profiles/*_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate
+    --pmc runs of this very command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+    for gfx950's wide coalesced reads; unit KB).  None when no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    try:
+        f, w = d["FETCH_SIZE"][family], d["WRITE_SIZE"][family]
+        return (2.0 * f["sum_kb"] / f["dispatches"] + w["sum_kb"] / w["dispatches"]) * 1024.0, os.path.basename(files[-1])
+    except KeyError:
+        return None, None
+
+
 def cpu_baseline(cfg, img, P, ratio, seconds_budget=25.0):
     """Reference-equivalent fp32 CPU step (oracle/vit_oracle.py: zero_grad -> forward ->
     L1 -> backward -> AdamW, eager, dropout 0.1) on a bounded sample."""
@@ -178,8 +195,11 @@ def main():
         dom = max(fam.items(), key=lambda kv: kv[1][1])
         name, (fl, ms, cnt) = dom
         ach = fl / (ms * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic_per_launch(name) if args.model == "vit_b" and args.batch == 256 else (None, None)
         roofline = {"kernel": name + "_kernel", "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                    "traffic": None if traffic is None else round(traffic), "traffic_unit": "bytes/launch (HBM, PMC)",
+                    "traffic_source": traffic_src,
                     "launches_per_step": cnt, "avg_launch_ms": round(ms / cnt, 4),
                     "alg_flops_per_launch": fl / cnt,
                     "families": {k: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1), "ms_per_step": round(v[1], 3), "launches": v[2]}
