@@ -130,6 +130,11 @@ def main():
     from vitssl_hip.optim import FusedAdamW
 
     cfg = MODELS[args.model]
+    # Host hygiene for the GPU phase: a GPU job gets a small CPU share; torch's default
+    # (one OpenMP worker per core, spin-waiting after every parallel CPU op) exhausts it and
+    # the whole process is throttled for tens of ms.  The CPU-baseline leg restores all cores.
+    from vit_core._runtime import limit_host_threads
+    host_threads = limit_host_threads()
     torch.manual_seed(42)                                   # identical init on every rank
     model = SimMIMViT(num_blocks=cfg["L"], input_shape=(3, args.img, args.img), embed_dim=cfg["D"], patch_size=args.patch,
                       num_heads=cfg["H"], mlp_dim=cfg["F"], dropout=args.dropout, mask_ratio=args.mask_ratio).to(dev).train()
@@ -207,6 +212,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        torch.set_num_threads(host_threads)
         cpu = cpu_baseline(cfg, args.img, args.patch, args.mask_ratio)
 
     if rank == 0:

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""DINO ViT-B/16 step timing (BASELINE configs[3] shapes: 2 x 224^2 global + 8 x 96^2 local
+crops, K = 65536, EMA m = 0.996, tau_s 0.1, tau_t 0.04, bf16 GEMMs, AdamW), synthetic data.
+Prints image-sets/s and the SURVEY section-8(d) algorithmic FLOP rate (437.8 GF per set)."""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "vit-ssl_amd"))
+import torch
+from vit_core.ssl.dino import DINOViT
+from vit_core.ssl.dino.loss import DINOLoss
+from vitssl_hip.optim import FusedAdamW
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=64)
+ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--warmup", type=int, default=3)
+ap.add_argument("--dropout", type=float, default=0.1)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+torch.manual_seed(42)
+m = DINOViT(12, (3, 224, 224), 768, 16, 12, 3072, a.dropout, 65536, 0.9).to(dev).train()
+opt = FusedAdamW(m.trainable_store(), lr=1e-4, weight_decay=1e-3)
+crit = DINOLoss(0.04, 0.1)
+B = a.batch
+views = [torch.rand(B, 3, 224, 224, device=dev) for _ in range(2)] + [torch.rand(B, 3, 96, 96, device=dev) for _ in range(8)]
+for _ in range(a.warmup):
+    loss = m.train_step(views, 2, crit, opt, None, 0.996)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(a.steps):
+    loss = m.train_step(views, 2, crit, opt, None, 0.996)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
+print(json.dumps({"workload": f"ViT-B/16 DINO 2x224+8x96 K=65536 batch {B}", "ms_per_step": round(dt * 1e3, 2),
+                  "image_sets_per_s": round(B / dt, 1), "alg_tflops": round(437.8e9 * B / dt / 1e12, 1),
+                  "mfma_util": round(437.8e9 * B / dt / 2.5e15, 4), "loss": round(float(loss), 5)}))

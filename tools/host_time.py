@@ -8,7 +8,9 @@ from vit_core.ssl.simmim import SimMIMViT
 from vitssl_hip.optim import FusedAdamW
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-m = SimMIMViT(12, (3, 224, 224), 768, 16, 12, 3072, 0.1, 0.6).to(dev).train()
+import os as _os
+_cfg = {"vit_b": (768, 12, 3072), "vit_s": (384, 6, 1536)}[_os.environ.get("MODEL", "vit_b")]
+m = SimMIMViT(12, (3, 224, 224), _cfg[0], 16, _cfg[1], _cfg[2], 0.1, 0.6).to(dev).train()
 opt = FusedAdamW(m.flat_store(), lr=1e-4, weight_decay=1e-3)
 x = torch.rand(256, 3, 224, 224, device=dev)
 for _ in range(3):

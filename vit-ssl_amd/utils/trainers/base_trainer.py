@@ -11,6 +11,8 @@ from abc import ABC, abstractmethod
 import torch
 import torch.distributed as dist
 
+from vit_core._runtime import limit_host_threads
+
 from .._config import cfg_get, to_plain
 from ..train_utils import make_criterion, make_optimizer, make_schedulers
 
@@ -29,6 +31,8 @@ class BaseTrainer(ABC):
         self.num_epochs = cfg_get(config, "training", "num_epochs")
         self.eval_interval = cfg_get(config, "eval", "interval", default=0)
 
+        if torch.device(device).type == "cuda":
+            limit_host_threads()
         self.criterion = self.create_criterion()
         self.optimizer = make_optimizer(config, model)
         self.schedulers = make_schedulers(config, self.optimizer, self.num_epochs, self.warmup_epochs * len(train_loader))

@@ -37,18 +37,35 @@ def as_f32(x: torch.Tensor) -> torch.Tensor:
     return x.contiguous()
 
 
+def limit_host_threads(n=None):
+    """Cap torch's intra-op CPU pool while the GPU engine drives the step.
+
+    A GPU job normally owns a small CPU share (cgroup quota).  torch sizes its OpenMP pool to
+    the machine's core count and the workers spin-wait after every parallel CPU op, which
+    burns the quota and gets the whole process throttled for the rest of the scheduler period
+    (measured on the MI355X box: 70-85 ms stalls at arbitrary host calls, ViT-S 48 -> 24
+    ms/step once capped).  `VITSSL_HOST_THREADS` overrides; returns the previous setting."""
+    prev = torch.get_num_threads()
+    if n is None:
+        n = int(os.environ.get("VITSSL_HOST_THREADS", "4"))
+    if n > 0:
+        torch.set_num_threads(min(n, prev))
+    return prev
+
+
 class StepPacer:
     """Bounds how far the host may run ahead of the GPU (in whole train steps).
 
-    Measured on MI355X / ROCm 7.2 (tools/host_time.py): with ~330 launches per step and an
-    unbounded launch queue the GPU itself runs 12-25 % slower (the runtime's in-flight
-    packet/signal pool is exhausted and refilled in bursts); with a sync after every step
-    the GPU idles while the host draws the next masks.  Keeping at most `depth` steps in
-    flight gets both right."""
+    Measured on MI355X / ROCm 7.2 (bench.py, ViT-B/16 and ViT-S/16 SimMIM, batch 256) once
+    the host pool is capped (limit_host_threads): look-ahead 0 (sync every step) 50.0 / 26.1
+    ms per step, 1: 46.8 / 23.6, 2: 45.1 / 22.9, 3: 44.8 / 21.3, 8: 44.8 / 21-22 (noisier).
+    Three steps in flight hide the host's mask bookkeeping and its launch jitter completely
+    (44.8 ms is also what a HIP-graph replay of the ViT-B step takes); deeper queues buy
+    nothing and only hold more pinned mask slots and event objects alive."""
 
     def __init__(self, depth=None):
         if depth is None:
-            depth = int(os.environ.get("VITSSL_STEP_LOOKAHEAD", "1"))
+            depth = int(os.environ.get("VITSSL_STEP_LOOKAHEAD", "3"))
         self.depth = max(0, depth)
         self.events = []
 

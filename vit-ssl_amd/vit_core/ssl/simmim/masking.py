@@ -12,12 +12,17 @@ import torch
 
 
 def draw_mask(batch_size: int, num_patches: int, mask_ratio: float, generator=None) -> torch.Tensor:
-    """Bool mask [B, N] on the CPU, bit-identical to the reference's CPU path."""
+    """Bool mask [B, N] on the CPU, bit-identical to the reference's CPU path.
+
+    Only the B tiny ``torch.randperm(N)`` draws touch torch (they define the parity
+    contract); the scatter into the mask is NumPy.  Any torch CPU op on the whole
+    50k-element mask would wake the full OpenMP pool, whose spin-waiting threads exhaust
+    the job's CPU quota on a GPU box (measured: 70-85 ms process stalls per step)."""
     num_masked = int(num_patches * mask_ratio)
-    mask = torch.zeros(batch_size, num_patches, dtype=torch.bool)
+    mask = np.zeros((batch_size, num_patches), dtype=np.bool_)
     for b in range(batch_size):
-        mask[b, torch.randperm(num_patches, generator=generator)[:num_masked]] = True
-    return mask
+        mask[b, torch.randperm(num_patches, generator=generator)[:num_masked].numpy()] = True
+    return torch.from_numpy(mask)
 
 
 def mask_indices_np(mask: torch.Tensor):
