@@ -53,7 +53,8 @@ using NtDeep = NtCfg<32, 2, 4, 4>;
 struct NtParams {
   const bf16_t* A;
   const bf16_t* B;
-  long long M;
+  long long M;        // one past the last row this launch may touch
+  long long m_begin;  // first row of this launch (row window [m_begin, M): tail peeling)
   int N, K;
   const float* bias;
   const void* aux;
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
   const int gw = min(p.group_n, p.tiles_n - cg * p.group_n);
   const int tile_m = rem / gw;
   const int tile_n = cg * p.group_n + (rem - tile_m * gw);
-  const long long m0 = (long long)tile_m * BM;
+  const long long m0 = p.m_begin + (long long)tile_m * BM;
   const int n0 = tile_n * BN;
 
   const int lane = threadIdx.x & 63;
@@ -403,6 +404,12 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
   }
 
   // ------------------------------------------------------------------ epilogue
+  // All global traffic of the epilogue goes through raw buffer instructions on a window
+  // that starts at the tile's first row: rows past M fall outside num_records and columns
+  // past N get the out-of-range offset, so loads return 0 and stores are dropped WITHOUT a
+  // branch.  That lets every residual / g' load of a 64-column half be issued back to back
+  // before the first use (the branchy form waited for each 16-byte load in turn: 32
+  // dependent HBM round trips per wave, measured +65 us on the N = K = 768 projection).
   float csum[4][4];
   if (p.colsum) {
 #pragma unroll
@@ -411,27 +418,48 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
       for (int r = 0; r < 4; ++r) csum[j][r] = 0.f;
   }
   const int g4 = lane >> 4;                       // lane group = 16-lane row of the wave
-  // bf16 outputs: tile columns (j, j+1) exchange halves between lane rows (g, g^1) with
-  // v_permlane16_swap so that every lane stores 16 contiguous bytes (8 columns).
+  // bf16 images: tile columns (j, j+1) exchange halves between lane rows (g, g^1) with
+  // v_permlane16_swap so that every lane moves 16 contiguous bytes (8 columns).
   const bool wide = (p.N & 7) == 0;
+  constexpr unsigned OOB = 0x80000000u;
+  const long long rows_left = p.M - m0;
+  auto window = [&](const void* base, int elt) {
+    const unsigned long long bytes = (unsigned long long)rows_left * (unsigned long long)p.N * (unsigned)elt;
+    const unsigned rec = bytes > 0x80000000ull ? 0x80000000u : (unsigned)bytes;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)base + m0 * p.N * elt), 0, (int)rec, 0x00020000);
+  };
+  const unsigned row_l = (unsigned)(wm * 128 + (lane & 15));      // + 16 i : row inside the tile
+  const unsigned un = (unsigned)p.N;
+  const int odd = g4 & 1;
 
-  auto store_bf16_pair = [&](bf16_t* base, long long m, int jp, const u32x2& w0, const u32x2& w1, bool ok0, bool ok1, bool okm) {
+  // byte offset of this lane's 16-byte piece of the bf16 image (wide form), row i, pair jp
+  auto off_bf16_wide = [&](int i, int jp) -> unsigned {
+    const int n = n0 + wn * 64 + (2 * jp + odd) * 16 + 4 * (g4 - odd);
+    return n < p.N ? ((row_l + 16u * i) * un + (unsigned)n) * 2u : OOB;
+  };
+  auto off_elem = [&](int i, int n, unsigned elt) -> unsigned {
+    return n < p.N ? ((row_l + 16u * i) * un + (unsigned)n) * elt : OOB;
+  };
+  auto store_bf16_pair = [&](__amdgpu_buffer_rsrc_t rs, int i, int jp, const u32x2& w0, const u32x2& w1) {
     if (wide) {
       // after the swap: even rows hold tile 2jp  cols 4g .. 4g+7, odd rows tile 2jp+1 cols 4(g-1) .. 4(g-1)+7
       auto lo = __builtin_amdgcn_permlane16_swap(w0[0], w1[0], false, false);
       auto hi = __builtin_amdgcn_permlane16_swap(w0[1], w1[1], false, false);
-      const int odd = g4 & 1;
-      const int n = n0 + wn * 64 + (2 * jp + odd) * 16 + 4 * (g4 - odd);
-      if (okm && n < p.N) {
-        u32x4 v = {lo[0], hi[0], lo[1], hi[1]};
-        *(u32x4*)(base + m * p.N + n) = v;
-      }
+      const u32x4 v = {lo[0], hi[0], lo[1], hi[1]};
+      __builtin_amdgcn_raw_buffer_store_b128(v, rs, off_bf16_wide(i, jp), 0, 0);
     } else {
       const int na = n0 + wn * 64 + (2 * jp) * 16 + 4 * g4;
-      if (okm && ok0) *(u32x2*)(base + m * p.N + na) = w0;
-      if (okm && ok1) *(u32x2*)(base + m * p.N + na + 16) = w1;
+      __builtin_amdgcn_raw_buffer_store_b64(w0, rs, off_elem(i, na, 2u), 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b64(w1, rs, off_elem(i, na + 16, 2u), 0, 0);
     }
   };
+
+  __amdgpu_buffer_rsrc_t rsOut0, rsOut1, rsAux;
+  if constexpr (EPI == VITSSL_EPI_BF16 || EPI == VITSSL_EPI_GELU || EPI == VITSSL_EPI_DGELU) rsOut0 = window(p.out0, 2);
+  if constexpr (EPI == VITSSL_EPI_F32 || EPI == VITSSL_EPI_RESID) rsOut0 = window(p.out0, 4);
+  if constexpr (EPI == VITSSL_EPI_GELU) rsOut1 = window(p.out1, 2);
+  if constexpr (EPI == VITSSL_EPI_RESID) rsAux = window(p.aux, 4);
+  if constexpr (EPI == VITSSL_EPI_DGELU) rsAux = window(p.aux, 2);
 
 #pragma unroll
   for (int jp = 0; jp < 2; ++jp) {
@@ -443,18 +471,50 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
       if (okA) biasA = *(const f32x4*)(p.bias + nA);
       if (okB) biasB = *(const f32x4*)(p.bias + nB);
     }
+    const int nn[2] = {nA, nB};
+    const bool okn[2] = {okA, okB};
+
+    // ---- operand prefetch for this half: every load in flight before the first use
+    f32x4 res[8][2];     // RESID: residual stream
+    u32x2 gpre[8][2];    // DGELU: g' in accumulator layout
+    if constexpr (EPI == VITSSL_EPI_RESID) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          res[i][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_elem(i, nn[h], 4u), 0, 0));
+    }
+    if constexpr (EPI == VITSSL_EPI_DGELU) {
+      if (wide) {
+        u32x4 raw[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_bf16_wide(i, jp), 0, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          // inverse of the store shuffle (the swap is an involution)
+          auto a = __builtin_amdgcn_permlane16_swap(raw[i][0], raw[i][2], false, false);
+          auto b = __builtin_amdgcn_permlane16_swap(raw[i][1], raw[i][3], false, false);
+          gpre[i][0] = u32x2{a[0], b[0]};
+          gpre[i][1] = u32x2{a[1], b[1]};
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) gpre[i][h] = __builtin_amdgcn_raw_buffer_load_b64(rsAux, off_elem(i, nn[h], 2u), 0, 0);
+      }
+    }
+
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const long long m = m0 + wm * 128 + i * 16 + (lane & 15);
       const bool okm = m < p.M;
       f32x4 v[2] = {acc[2 * jp][i] + biasA, acc[2 * jp + 1][i] + biasB};
-      const int nn[2] = {nA, nB};
-      const bool okn[2] = {okA, okB};
 
       if constexpr (EPI == VITSSL_EPI_BF16) {
         const u32x2 w0 = {pack_bf2(v[0][0], v[0][1]), pack_bf2(v[0][2], v[0][3])};
         const u32x2 w1 = {pack_bf2(v[1][0], v[1][1]), pack_bf2(v[1][2], v[1][3])};
-        store_bf16_pair((bf16_t*)p.out0, m, jp, w0, w1, okA, okB, okm);
+        store_bf16_pair(rsOut0, i, jp, w0, w1);
       } else if constexpr (EPI == VITSSL_EPI_GELU) {
         // u = bf16(acc + bias) (never stored); out1 = a = keep*scale*gelu(u) feeds the next
         // GEMM; out0 = g' = keep*scale*gelu'(u) is what the backward dGELU epilogue needs.
@@ -473,45 +533,46 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
           a[h] = u32x2{pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
           gp[h] = u32x2{pack_bf2(d[0], d[1]), pack_bf2(d[2], d[3])};
         }
-        store_bf16_pair((bf16_t*)p.out0, m, jp, gp[0], gp[1], okA, okB, okm);
-        store_bf16_pair((bf16_t*)p.out1, m, jp, a[0], a[1], okA, okB, okm);
+        store_bf16_pair(rsOut0, i, jp, gp[0], gp[1]);
+        store_bf16_pair(rsOut1, i, jp, a[0], a[1]);
       } else if constexpr (EPI == VITSSL_EPI_DGELU) {
         // du = acc * g'  (g' already carries the dropout mask and its scale)
         u32x2 w[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          u32x2 gpv = {0u, 0u};
-          if (okm && okn[h]) gpv = *(const u32x2*)((const bf16_t*)p.aux + m * p.N + nn[h]);
+          const u32x2 gpv = gpre[i][h];
           v[h][0] *= bf_lo(gpv[0]);
           v[h][1] *= bf_hi(gpv[0]);
           v[h][2] *= bf_lo(gpv[1]);
           v[h][3] *= bf_hi(gpv[1]);
           w[h] = u32x2{pack_bf2(v[h][0], v[h][1]), pack_bf2(v[h][2], v[h][3])};
         }
-        store_bf16_pair((bf16_t*)p.out0, m, jp, w[0], w[1], okA, okB, okm);
-      } else {
+        store_bf16_pair(rsOut0, i, jp, w[0], w[1]);
+      } else if constexpr (EPI == VITSSL_EPI_F32) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[h]), rsOut0, off_elem(i, nn[h], 4u), 0, 0);
+      } else if constexpr (EPI == VITSSL_EPI_RESID) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (p.drop_on) {
+            float mult[4];
+            drop_mult4(p.dk, (unsigned long long)(m * p.N + nn[h]) >> 2, mult);
+            v[h][0] *= mult[0]; v[h][1] *= mult[1]; v[h][2] *= mult[2]; v[h][3] *= mult[3];
+          }
+          v[h] += res[i][h];
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[h]), rsOut0, off_elem(i, nn[h], 4u), 0, 0);
+        }
+      } else {   // VITSSL_EPI_EMBED (one launch per step: plain addressing)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           if (!(okm && okn[h])) continue;
-          const long long e = m * p.N + nn[h];
-          if constexpr (EPI == VITSSL_EPI_F32) {
-            *(f32x4*)((float*)p.out0 + e) = v[h];
-          } else if constexpr (EPI == VITSSL_EPI_RESID) {
-            if (p.drop_on) {
-              float mult[4];
-              drop_mult4(p.dk, (unsigned long long)e >> 2, mult);
-              v[h][0] *= mult[0]; v[h][1] *= mult[1]; v[h][2] *= mult[2]; v[h][3] *= mult[3];
-            }
-            v[h] += *(const f32x4*)((const float*)p.aux + e);
-            *(f32x4*)((float*)p.out0 + e) = v[h];
-          } else if constexpr (EPI == VITSSL_EPI_EMBED) {
-            const long long img = m / p.embed.tokens;
-            const int rin = (int)(m - img * p.embed.tokens);
-            if (p.embed.mask && p.embed.mask[m]) v[h] = *(const f32x4*)(p.embed.mask_token + nn[h]);
-            v[h] += *(const f32x4*)(p.embed.pos + (long long)(p.embed.tok_offset + rin) * p.N + nn[h]);
-            const long long orow = img * p.embed.out_tokens + p.embed.tok_offset + rin;
-            *(f32x4*)((float*)p.out0 + orow * p.N + nn[h]) = v[h];
-          }
+          const long long img = m / p.embed.tokens;
+          const int rin = (int)(m - img * p.embed.tokens);
+          if (p.embed.mask && p.embed.mask[m]) v[h] = *(const f32x4*)(p.embed.mask_token + nn[h]);
+          v[h] += *(const f32x4*)(p.embed.pos + (long long)(p.embed.tok_offset + rin) * p.N + nn[h]);
+          const long long orow = img * p.embed.out_tokens + p.embed.tok_offset + rin;
+          *(f32x4*)((float*)p.out0 + orow * p.N + nn[h]) = v[h];
         }
       }
       if (p.colsum) {
@@ -554,7 +615,7 @@ int launch_cfg(NtParams p, hipStream_t s) {
     }
     attr_done = true;
   }
-  p.tiles_m = (int)ceil_div64(p.M, CFG::BM);
+  p.tiles_m = (int)ceil_div64(p.M - p.m_begin, CFG::BM);
   p.tiles_n = (int)ceil_div64(p.N, CFG::BN);
   const int want = (int)((2 * 1024 * 1024) / ((long long)CFG::BN * p.K * 2));   // panels of a group <= ~2 MiB of L2
   if (p.tiles_n <= 4) p.group_n = p.tiles_n;
@@ -596,24 +657,7 @@ int nt_tile_override() {
 }
 
 template <int EPI>
-int launch_nt(const NtParams& p, hipStream_t s) {
-  int mode = nt_tile_override();
-  bool small;
-  if (mode == 1) small = false;
-  else if (mode == 2) small = true;
-  else {
-    // heavy epilogues want co-resident workgroups; so do grids that fill the 256 CUs badly
-    const long long big_tiles = ceil_div64(p.M, 256) * ceil_div64(p.N, 256);
-    const double rounds = (double)big_tiles / 256.0;
-    const double eff = rounds / (double)((long long)(rounds + 0.999999));
-    // Measured on MI355X (tools/bench_gemm.py, round 1): SMALL loses 10-25 % on every
-    // ViT-B shape, heavy epilogues included (co-resident workgroups start in lock-step, so
-    // their epilogues still coincide).  It only pays for tiny grids.
-    (void)eff;
-    small = big_tiles < 64;
-  }
-  if (mode == 3) return launch_cfg<EPI, NtDeep>(p, s);
-  if (small) return launch_cfg<EPI, NtSmall>(p, s);
+int launch_big(const NtParams& p, hipStream_t s) {
   static int ph = -1;   // MFMA clusters per K-step in the BIG loop (VITSSL_NT_PHASES, developer knob)
   if (ph < 0) {
     const char* e = getenv("VITSSL_NT_PHASES");
@@ -623,6 +667,56 @@ int launch_nt(const NtParams& p, hipStream_t s) {
   return ph == 4 ? launch_cfg<EPI, NtBig, 4>(p, s) : launch_cfg<EPI, NtBig, 2>(p, s);
 }
 
+// Tail peeling.  Every 256x256 tile costs the same and one workgroup owns a CU, so a grid of
+// T tiles takes ceil(T / 256) rounds: 588 tiles (N = 768, M = 50176) pay for 3 rounds and use
+// 2.3.  When the last round is badly filled, the BIG kernel takes the tile rows that make
+// whole rounds and the remaining rows go to a second launch with the 256x128 SMALL tiles
+// (half the work per tile, co-resident workgroups), which costs about two thirds of a round.
+// Row indices stay global in both launches (dropout counters, embedding rows, bounds).
+// Measured (tools/bench_gemm.py, M = 50176): N=768 K=768 75.4 -> 78.2 us, N=3072 K=768
+// 256 -> 264 us, N=768 K=3072 232 -> 244 us: the "rounds" model is wrong for this kernel --
+// it is bound by the L2 -> LDS request path, so the tiles of an under-filled last round run
+// faster, and the second launch adds a drain + ramp.  Kept as a developer knob, default off.
+// Returns the number of rows for the BIG launch, or M when peeling does not pay.
+long long peel_rows(long long M, int N) {
+  static int knob = -1;
+  if (knob < 0) {
+    const char* e = getenv("VITSSL_NT_PEEL");
+    knob = e ? atoi(e) : 0;   // measured: 2-9 % SLOWER on every ViT-B shape (see below)
+  }
+  if (!knob) return M;
+  const long long tm = ceil_div64(M, 256), tn = ceil_div64(N, 256);
+  const long long tiles = tm * tn;
+  const long long full = tiles / 256;
+  if (full < 1 || tiles % 256 == 0) return M;
+  const long long tm_big = full * 256 / tn;
+  if (tm_big < 1 || tm_big >= tm) return M;
+  const long long rest_rows = M - tm_big * 256;
+  const long long small_tiles = ceil_div64(rest_rows, 256) * ceil_div64(N, 128);
+  const double tail = 0.68 * (double)ceil_div64(small_tiles, 256);
+  return ((double)full + tail < (double)(full + 1) - 0.15) ? tm_big * 256 : M;
+}
+
+template <int EPI>
+int launch_nt(const NtParams& p, hipStream_t s) {
+  int mode = nt_tile_override();
+  if (mode == 1) return launch_big<EPI>(p, s);
+  if (mode == 2) return launch_cfg<EPI, NtSmall>(p, s);
+  if (mode == 3) return launch_cfg<EPI, NtDeep>(p, s);
+  // Measured on MI355X (tools/bench_gemm.py, round 1): as the ONLY tile, SMALL loses 10-25 %
+  // on every ViT-B shape, heavy epilogues included.  It pays for tiny grids and for tails.
+  const long long big_tiles = ceil_div64(p.M, 256) * ceil_div64(p.N, 256);
+  if (big_tiles < 64) return launch_cfg<EPI, NtSmall>(p, s);
+  const long long rows_big = peel_rows(p.M, p.N);
+  if (rows_big >= p.M) return launch_big<EPI>(p, s);
+  NtParams head = p, tail = p;
+  head.M = rows_big;
+  tail.m_begin = rows_big;
+  int rc = launch_big<EPI>(head, s);
+  if (rc != VITSSL_OK) return rc;
+  return launch_cfg<EPI, NtSmall>(tail, s);
+}
+
 }  // namespace
 
 extern "C" int vitssl_gemm_bf16_nt(const vitssl_gemm_t* g, void* stream) {
@@ -630,12 +724,14 @@ extern "C" int vitssl_gemm_bf16_nt(const vitssl_gemm_t* g, void* stream) {
   VS_CHECK_ARG(g->M > 0 && g->N > 0 && g->K > 0, "gemm_nt: empty problem M=%lld N=%d K=%d", (long long)g->M, g->N, g->K);
   VS_CHECK_ARG(g->K % 64 == 0, "gemm_nt: K=%d must be a multiple of 64", g->K);
   VS_CHECK_ARG(g->N % 4 == 0, "gemm_nt: N=%d must be a multiple of 4", g->N);
+  VS_CHECK_ARG(g->N <= (1 << 20), "gemm_nt: N=%d exceeds 2^20 (epilogue windows use 32-bit byte offsets)", g->N);
   VS_CHECK_ARG((unsigned long long)g->M * g->K * 2ull < (1ull << 31) && (unsigned long long)g->N * g->K * 2ull < (1ull << 31),
                "gemm_nt: operand larger than 2 GiB (M=%lld N=%d K=%d)", (long long)g->M, g->N, g->K);
   NtParams p;
   p.A = (const bf16_t*)g->A;
   p.B = (const bf16_t*)g->B;
   p.M = g->M;
+  p.m_begin = 0;
   p.N = g->N;
   p.K = g->K;
   p.bias = g->bias;
