@@ -24,6 +24,7 @@
 // produces delta = rowsum(dO*O) for its queries from the fragments it already holds) and
 // dK/dV (each wave owns 32 keys, sweeps queries).  P is recomputed from the saved
 // log-sum-exp; nothing of size N^2 ever reaches HBM.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -97,33 +98,51 @@ __device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 
 // ------------------------------------------------------------------ forward
-// in-register row softmax of one 16-query tile: s holds S^T[key = 16kt + 4g + r][q = lane&15]
+// Softmax VALU budget.  The kernels are VALU-bound, not MFMA-bound (rocprofv3 PMC, forward:
+// 13.9 VALU instructions per score element against 1/14 MFMA), so every per-element
+// instruction counts:
+//   * the key mask costs nothing in the loops: the accumulators of the last two 16-key
+//     tiles (the only ones that can hold keys >= N, since 32*NS - 32 < N) START at -inf
+//     for those keys, and exp2(-inf) = 0;
+//   * 1/sqrt(dh) and log2(e) are folded into one fused multiply-add in front of v_exp_f32
+//     (packed: v_pk_fma_f32 handles two scores), the row maximum is taken on raw scores;
+//   * probabilities stay unnormalised (in (0, 1]) through the P.V product and the 64 outputs
+//     of a query are scaled by 1/sum instead of its up to 256 probabilities.
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float SCALE = 0.125f;                  // 1/sqrt(64)
+constexpr float SCALE_LOG2E = SCALE * LOG2E;
+
+// -inf for the keys >= N of 16-key tile kt (lane holds keys 16kt + 4g + r), else 0
+__device__ __forceinline__ f32x4 key_mask_init(int kt, int g, int N) {
+  f32x4 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = (kt * 16 + 4 * g + r < N) ? 0.f : -INFINITY;
+  return v;
+}
+
+// in-register row softmax of one 16-query tile on RAW scores: s holds
+// S^T[key = 16kt + 4g + r][q = lane&15] (masked keys = -inf); on return s = exp(scale*(s - max))
+// (unnormalised), m_out = raw row maximum, sum_out = row sum of s.
 template <int NKT>
-__device__ __forceinline__ void softmax_tile(f32x4 (&s)[NKT], int N, int g, float scale, float& m_out, float& sum_out) {
+__device__ __forceinline__ void softmax_tile(f32x4 (&s)[NKT], float& m_out, float& sum_out) {
   float m = -INFINITY;
 #pragma unroll
-  for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int key = kt * 16 + 4 * g + r;
-      s[kt][r] = key < N ? s[kt][r] * scale : -INFINITY;
-      m = fmaxf(m, s[kt][r]);
-    }
+  for (int kt = 0; kt < NKT; ++kt) m = fmaxf(fmaxf(m, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
   m = fmaxf(m, __shfl_xor(m, 16, 64));
   m = fmaxf(m, __shfl_xor(m, 32, 64));
-  float sum = 0.f;
+  const float mc = -m * SCALE_LOG2E;
+  const f32x4 c4 = {SCALE_LOG2E, SCALE_LOG2E, SCALE_LOG2E, SCALE_LOG2E}, m4 = {mc, mc, mc, mc};
+  f32x4 part = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int kt = 0; kt < NKT; ++kt)
+  for (int kt = 0; kt < NKT; ++kt) {
+    const f32x4 e = __builtin_elementwise_fma(s[kt], c4, m4);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      s[kt][r] = __expf(s[kt][r] - m);
-      sum += s[kt][r];
-    }
+    for (int r = 0; r < 4; ++r) s[kt][r] = __builtin_amdgcn_exp2f(e[r]);
+    part += s[kt];
+  }
+  float sum = (part[0] + part[1]) + (part[2] + part[3]);
   sum += __shfl_xor(sum, 16, 64);
   sum += __shfl_xor(sum, 32, 64);
-  const float inv = 1.0f / sum;
-#pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) s[kt] *= inv;
   m_out = m;
   sum_out = sum;
 }
@@ -147,8 +166,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, li = lane & 15;
-  const float scale = 0.125f;  // 1/sqrt(64)
   const int nqp = (N + 31) >> 5;   // pairs of 16-query tiles
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 tail0 = key_mask_init(NKT - 2, g, N), tail1 = key_mask_init(NKT - 1, g, N);
 
   // Q fragments of this wave's first pair (ordinary loads) and the K tile (LDS-DMA) are
   // awaited together; the V tile's DMA is issued only then, so it lands underneath the
@@ -188,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     for (int kt = 0; kt < NKT; ++kt) {
       const bf16x8 k0 = lds_frag(Kt, kt * 16 + li, 0, lane);
       const bf16x8 k1 = lds_frag(Kt, kt * 16 + li, 1, lane);
-      f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
+      f32x4 a = kt == NKT - 2 ? tail0 : (kt == NKT - 1 ? tail1 : zero4), c = a;
       a = MFMA16(k0, qf[0][0], a);
       c = MFMA16(k0, qf[1][0], c);
       a = MFMA16(k1, qf[0][1], a);
@@ -196,13 +216,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
       s0[kt] = a;
       s1[kt] = c;
     }
-    float m[2], sum[2];
-    softmax_tile<NKT>(s0, N, g, scale, m[0], sum[0]);
-    softmax_tile<NKT>(s1, N, g, scale, m[1], sum[1]);
+    float m[2], sum[2], inv[2];
+    softmax_tile<NKT>(s0, m[0], sum[0]);
+    softmax_tile<NKT>(s1, m[1], sum[1]);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
+      inv[t] = 1.0f / sum[t];
       if (q[t] < N) {
-        if (g == 0) lse[((long long)b * H + h) * N + q[t]] = m[t] + __logf(sum[t]);
+        if (g == 0) lse[((long long)b * H + h) * N + q[t]] = m[t] * SCALE + __logf(sum[t]);
         if (probs) {
           float* pr = probs + (((long long)b * H + h) * N + q[t]) * N;
 #pragma unroll
@@ -210,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int key = kt * 16 + 4 * g + r;
-              if (key < N) pr[key] = t == 0 ? s0[kt][r] : s1[kt][r];
+              if (key < N) pr[key] = (t == 0 ? s0[kt][r] : s1[kt][r]) * inv[t];
             }
         }
       }
@@ -244,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         bf16_t* og = out + ((long long)b * N + q[t]) * (H * DH) + h * DH;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          const f32x4 o = t == 0 ? o0[dt] : o1[dt];
+          const f32x4 o = (t == 0 ? o0[dt] : o1[dt]) * inv[t];
           u32x2 w = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
           *(u32x2*)(og + dt * 16 + 4 * g) = w;
         }
@@ -277,9 +298,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16_t* __restr
     dma_tile<8>(Dt, dog, (long long)H * DH, N, Np, wv, threadIdx.x & 63);
   }
   for (int i = threadIdx.x; i < Np; i += 512) {
-    // padded queries: lse = +inf makes p = exp(0 - inf) = 0
-    lse_s[i] = i < N ? lse[((long long)b * H + h) * N + i] : INFINITY;
-    del_s[i] = i < N ? delta[((long long)b * H + h) * N + i] : 0.f;
+    // stored pre-multiplied (log2(e), 1/sqrt(dh)) so that the loop needs one fused
+    // multiply-add per score; padded queries: +inf makes p = exp2(x - inf) = 0
+    lse_s[i] = i < N ? lse[((long long)b * H + h) * N + i] * LOG2E : INFINITY;
+    del_s[i] = i < N ? delta[((long long)b * H + h) * N + i] * SCALE : 0.f;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -288,7 +310,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16_t* __restr
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wave * 32 >= N) return;  // wave-uniform; no barrier below
   const int g = lane >> 4, li = lane & 15;
-  const float scale = 0.125f;
+  const f32x4 c4 = {SCALE_LOG2E, SCALE_LOG2E, SCALE_LOG2E, SCALE_LOG2E}, sc4 = {SCALE, SCALE, SCALE, SCALE};
 
   bf16x8 kf[2][2], vf[2][2];
 #pragma unroll
@@ -316,6 +338,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16_t* __restr
       const int qrow = qs * 32 + t * 16 + li;
       const bf16x8 qa0 = lds_frag(Qt, qrow, 0, lane), qa1 = lds_frag(Qt, qrow, 1, lane);
       const bf16x8 da0 = lds_frag(Dt, qrow, 0, lane), da1 = lds_frag(Dt, qrow, 1, lane);
+      // this lane's four queries of the tile: -lse*log2(e) and -delta*scale
+      const f32x4 nl = -*(const f32x4*)(lse_s + qs * 32 + t * 16 + 4 * g);
+      const f32x4 nd = -*(const f32x4*)(del_s + qs * 32 + t * 16 + 4 * g);
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
         f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
@@ -323,13 +348,11 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16_t* __restr
         a = MFMA16(qa1, kf[kt][1], a);
         c = MFMA16(da0, vf[kt][0], c);
         c = MFMA16(da1, vf[kt][1], c);
+        // keys >= N need no mask here: their dK / dV rows are never stored
+        const f32x4 e = __builtin_elementwise_fma(a, c4, nl);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int qq = qs * 32 + t * 16 + 4 * g + r;
-          const float pv = __expf(a[r] * scale - lse_s[qq]);
-          p[t][kt][r] = pv;
-          ds[t][kt][r] = pv * (c[r] - del_s[qq]) * scale;
-        }
+        for (int r = 0; r < 4; ++r) p[t][kt][r] = __builtin_amdgcn_exp2f(e[r]);
+        ds[t][kt] = p[t][kt] * __builtin_elementwise_fma(c, sc4, nd);
       }
     }
 #pragma unroll
@@ -382,8 +405,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, li = lane & 15;
-  const float scale = 0.125f;
   const int nqp = (N + 31) >> 5;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 tail0 = key_mask_init(NKT - 2, g, N), tail1 = key_mask_init(NKT - 1, g, N);
+  const f32x4 c4 = {SCALE_LOG2E, SCALE_LOG2E, SCALE_LOG2E, SCALE_LOG2E}, sc4 = {SCALE, SCALE, SCALE, SCALE};
   dma_tile<4>(Kt, kg, stride, N, Np, wave, lane);
   dma_tile<4>(Vt, vg, stride, N, Np, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -415,12 +440,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
       dl[t] = part;
       if (q[t] < N && g == 0) delta[((long long)b * H + h) * N + q[t]] = part;
     }
+    // per-query constants of the fused score pipeline; padded queries: lse = +inf -> p = 0
+    const float nl0 = -l[0] * LOG2E, nl1 = -l[1] * LOG2E, nd0 = -dl[0] * SCALE, nd1 = -dl[1] * SCALE;
+    const f32x4 nl0v = {nl0, nl0, nl0, nl0}, nl1v = {nl1, nl1, nl1, nl1};
+    const f32x4 nd0v = {nd0, nd0, nd0, nd0}, nd1v = {nd1, nd1, nd1, nd1};
     f32x4 ds0[NKT], ds1[NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       const bf16x8 k0 = lds_frag(Kt, kt * 16 + li, 0, lane), k1 = lds_frag(Kt, kt * 16 + li, 1, lane);
       const bf16x8 v0 = lds_frag(Vt, kt * 16 + li, 0, lane), v1 = lds_frag(Vt, kt * 16 + li, 1, lane);
-      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, c0 = a0, a1 = a0, c1 = a0;
+      // masked keys start at -inf: p = exp2(-inf) = 0 (V rows >= N are zero, so dP stays finite)
+      f32x4 a0 = kt == NKT - 2 ? tail0 : (kt == NKT - 1 ? tail1 : zero4), a1 = a0, c0 = zero4, c1 = zero4;
       a0 = MFMA16(k0, qf[0][0], a0);
       a1 = MFMA16(k0, qf[1][0], a1);
       c0 = MFMA16(v0, df[0][0], c0);
@@ -429,14 +459,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
       a1 = MFMA16(k1, qf[1][1], a1);
       c0 = MFMA16(v1, df[0][1], c0);
       c1 = MFMA16(v1, df[1][1], c1);
+      const f32x4 e0 = __builtin_elementwise_fma(a0, c4, nl0v), e1 = __builtin_elementwise_fma(a1, c4, nl1v);
+      f32x4 p0, p1;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const bool valid = kt * 16 + 4 * g + r < N;
-        const float p0 = valid ? __expf(a0[r] * scale - l[0]) : 0.f;
-        const float p1 = valid ? __expf(a1[r] * scale - l[1]) : 0.f;
-        ds0[kt][r] = p0 * (c0[r] - dl[0]) * scale;
-        ds1[kt][r] = p1 * (c1[r] - dl[1]) * scale;
+        p0[r] = __builtin_amdgcn_exp2f(e0[r]);
+        p1[r] = __builtin_amdgcn_exp2f(e1[r]);
       }
+      ds0[kt] = p0 * __builtin_elementwise_fma(c0, sc4, nd0v);
+      ds1[kt] = p1 * __builtin_elementwise_fma(c1, sc4, nd1v);
       __builtin_amdgcn_sched_barrier(0);   // keep fragment live ranges per key tile (256-VGPR budget)
     }
     f32x4 dq0[4], dq1[4];
@@ -471,6 +502,193 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
   }
 }
 
+// ------------------------------------------------------------------ backward, fused (one launch)
+// grid = B*H, 512 threads.  Wave w < NS owns keys [32w, 32w+32): it holds their K / V row
+// fragments in registers, sweeps the queries in steps of 32 and accumulates dK / dV exactly
+// like the split dK/dV kernel.  The dS tile of every step is also dropped (bf16) into a
+// double-buffered LDS exchange image [32 queries][Np keys]; after one barrier the eight
+// waves each take one (16-query tile, 16-column slice) of dQ for those 32 queries and
+// contract over ALL keys from that image -- S and dP are computed once instead of twice,
+// Q / K / V / dO are read from HBM once, there are no atomics and no N^2 traffic.
+// delta = rowsum(dO * O) is computed in the prologue.
+template <int NS>
+__global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ outp,
+                                                             const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                             bf16_t* __restrict__ dqkv, int N, int H) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int Np = 32 * NS;
+  constexpr int SROW = Np * 2 + 16;     // exchange-image row (bytes); +16 makes the 8-byte column reads conflict-free
+  char* Qt = smem;
+  char* Dt = Qt + Np * ROWB;
+  char* Kt = Dt + Np * ROWB;
+  char* Sx = Kt + Np * ROWB;            // 2 x [32][SROW]
+  float* lse_s = (float*)(Sx + 2 * 32 * SROW);
+  float* del_s = lse_s + Np;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const long long stride = 3LL * H * DH, ostride = (long long)H * DH;
+  const bf16_t* qg = qkv + (long long)b * N * stride + h * DH;
+  const bf16_t* kg = qg + (long long)H * DH;
+  const bf16_t* vg = kg + (long long)H * DH;
+  const bf16_t* dog = dout + (long long)b * N * ostride + h * DH;
+  const bf16_t* og = outp + (long long)b * N * ostride + h * DH;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const bool has_keys = wave < NS;      // wave-uniform; such a wave has at least one key < N
+
+  // ---- prologue: delta / lse rows, own K / V fragments, then the three LDS tiles
+  {
+    const int row = threadIdx.x >> 1, half = threadIdx.x & 1;   // 2 threads per query row (Np <= 256)
+    float part = 0.f;
+    if (row < N) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32x4 ov = *(const u32x4*)(og + (long long)row * ostride + half * 32 + j * 8);
+        const u32x4 dv = *(const u32x4*)(dog + (long long)row * ostride + half * 32 + j * 8);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) part += bf_lo(ov[w]) * bf_lo(dv[w]) + bf_hi(ov[w]) * bf_hi(dv[w]);
+      }
+    }
+    part += __shfl_xor(part, 1, 64);
+    if (half == 0 && row < Np) {
+      // pre-multiplied (log2(e), 1/sqrt(dh)); padded queries: +inf makes p = exp2(x - inf) = 0
+      lse_s[row] = row < N ? lse[((long long)b * H + h) * N + row] * LOG2E : INFINITY;
+      del_s[row] = row < N ? part * SCALE : 0.f;
+    }
+  }
+  bf16x8 kf[2][2], vf[2][2];
+  f32x4 kinit[2];
+  if (has_keys) {
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      const int key = wave * 32 + kt * 16 + li;
+      const float mi = key < N ? 0.f : -INFINITY;   // masked keys: scores start at -inf -> p = dS = 0
+      kinit[kt] = f32x4{mi, mi, mi, mi};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        kf[kt][kk] = glb_frag(kg, stride, key, kk, N, lane);
+        vf[kt][kk] = glb_frag(vg, stride, key, kk, N, lane);
+      }
+    }
+  }
+  dma_tile<8>(Qt, qg, stride, N, Np, wave, lane);
+  dma_tile<8>(Dt, dog, ostride, N, Np, wave, lane);
+  dma_tile<8>(Kt, kg, stride, N, Np, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const f32x4 c4 = {SCALE_LOG2E, SCALE_LOG2E, SCALE_LOG2E, SCALE_LOG2E}, sc4 = {SCALE, SCALE, SCALE, SCALE};
+  f32x4 dv[4][2], dk[4][2];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      dv[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dk[dt][kt] = dv[dt][kt];
+    }
+  const int qt_w = wave >> 2, dt_w = wave & 3;     // this wave's dQ tile inside a 32-query step
+
+  // dQ^T[d][q] = sum_key K[key][d] dS[q][key] for q-tile qt_w, columns 16 dt_w .. +15 of
+  // the 32 queries of step `qs`, from exchange image `sx`.  Two accumulators halve the
+  // dependent-MFMA chain.
+  auto dq_tile = [&](const char* sx, int qs) {
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    const char* rowp = sx + (16 * qt_w + li) * SROW + 8 * g;
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      const u32x2 lo = *(const u32x2*)(rowp + 64 * st);        // keys 32st + 4g .. +3
+      const u32x2 hi = *(const u32x2*)(rowp + 64 * st + 32);   // keys 32st + 16 + 4g .. +3
+      const u32x4 w = {lo[0], lo[1], hi[0], hi[1]};
+      if (st & 1) acc1 = MFMA16(tr_frag(Kt, st, dt_w, lane), __builtin_bit_cast(bf16x8, w), acc1);
+      else acc0 = MFMA16(tr_frag(Kt, st, dt_w, lane), __builtin_bit_cast(bf16x8, w), acc0);
+    }
+    const f32x4 acc = acc0 + acc1;
+    const int q = qs * 32 + 16 * qt_w + li;
+    if (q < N) {
+      const u32x2 w = {pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3])};
+      *(u32x2*)(dqkv + ((long long)b * N + q) * stride + h * DH + dt_w * 16 + 4 * g) = w;
+    }
+  };
+
+  // Software pipeline: the dQ tile of step qs-1 (independent MFMAs and LDS reads) is issued
+  // between the score MFMAs of step qs and their exp / dS arithmetic, so the matrix pipe has
+  // work while the VALU runs the softmax recompute.  One barrier per step: it publishes the
+  // dS columns of step qs and, because every wave's dQ reads of step qs-1 precede it in
+  // program order, also frees the other exchange buffer for step qs+1.
+#pragma unroll 1
+  for (int qs = 0; qs < NS; ++qs) {
+    char* sx = Sx + (qs & 1) * 32 * SROW;
+    if (has_keys) {
+      f32x4 p[2][2], ds[2][2];  // [query tile in step][key tile]
+      f32x4 a[2][2], c[2][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int qrow = qs * 32 + t * 16 + li;
+        const bf16x8 qa0 = lds_frag(Qt, qrow, 0, lane), qa1 = lds_frag(Qt, qrow, 1, lane);
+        const bf16x8 da0 = lds_frag(Dt, qrow, 0, lane), da1 = lds_frag(Dt, qrow, 1, lane);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          a[t][kt] = kinit[kt];
+          c[t][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          a[t][kt] = MFMA16(qa0, kf[kt][0], a[t][kt]);
+          a[t][kt] = MFMA16(qa1, kf[kt][1], a[t][kt]);
+          c[t][kt] = MFMA16(da0, vf[kt][0], c[t][kt]);
+          c[t][kt] = MFMA16(da1, vf[kt][1], c[t][kt]);
+        }
+      }
+      if (qs > 0) dq_tile(Sx + ((qs - 1) & 1) * 32 * SROW, qs - 1);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const f32x4 nl = -*(const f32x4*)(lse_s + qs * 32 + t * 16 + 4 * g);
+        const f32x4 nd = -*(const f32x4*)(del_s + qs * 32 + t * 16 + 4 * g);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          const f32x4 e = __builtin_elementwise_fma(a[t][kt], c4, nl);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) p[t][kt][r] = __builtin_amdgcn_exp2f(e[r]);
+          ds[t][kt] = p[t][kt] * __builtin_elementwise_fma(c[t][kt], sc4, nd);
+          // exchange image: row = query 16t + 4g + r of the step, column = key 32w + 16kt + li
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            *(bf16_t*)(sx + (16 * t + 4 * g + r) * SROW + (32 * wave + 16 * kt + li) * 2) = f2bf(ds[t][kt][r]);
+        }
+      }
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        const bf16x8 pf = pack_frag(p[0][kt], p[1][kt]);
+        const bf16x8 sf = pack_frag(ds[0][kt], ds[1][kt]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          dv[dt][kt] = MFMA16(tr_frag(Dt, qs, dt, lane), pf, dv[dt][kt]);
+          dk[dt][kt] = MFMA16(tr_frag(Qt, qs, dt, lane), sf, dk[dt][kt]);
+        }
+      }
+    } else if (qs > 0) {
+      dq_tile(Sx + ((qs - 1) & 1) * 32 * SROW, qs - 1);
+    }
+    __syncthreads();   // every key owner's dS columns of this step are in the image
+  }
+  dq_tile(Sx + ((NS - 1) & 1) * 32 * SROW, NS - 1);
+  if (has_keys) {
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      const int key = wave * 32 + kt * 16 + li;
+      if (key < N) {
+        bf16_t* dkg = dqkv + ((long long)b * N + key) * stride + (long long)H * DH + h * DH;
+        bf16_t* dvg = dkg + (long long)H * DH;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          u32x2 wk = {pack_bf2(dk[dt][kt][0], dk[dt][kt][1]), pack_bf2(dk[dt][kt][2], dk[dt][kt][3])};
+          u32x2 wv = {pack_bf2(dv[dt][kt][0], dv[dt][kt][1]), pack_bf2(dv[dt][kt][2], dv[dt][kt][3])};
+          *(u32x2*)(dkg + dt * 16 + 4 * g) = wk;
+          *(u32x2*)(dvg + dt * 16 + 4 * g) = wv;
+        }
+      }
+    }
+  }
+}
+
+
 template <typename K>
 int ensure_lds(K kernel, int bytes, bool* done, const char* who) {
   if (*done || bytes <= 48 * 1024) return VITSSL_OK;
@@ -493,9 +711,27 @@ int launch_fwd(const bf16_t* qkv, bf16_t* out, float* lse, float* probs, int B, 
   return VITSSL_OK;
 }
 
+// VITSSL_ATTN_BWD=split selects the two-launch backward (developer knob for A/B timing)
+bool attn_bwd_split() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("VITSSL_ATTN_BWD");
+    v = (e && !strcmp(e, "split")) ? 1 : 0;
+  }
+  return v == 1;
+}
+
 template <int NS>
 int launch_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, float* delta, bf16_t* dqkv, int B,
                int N, int H, hipStream_t s) {
+  if (!attn_bwd_split()) {
+    static bool done_f = false;
+    const int lds_f = 3 * NS * 32 * ROWB + 2 * 32 * (NS * 64 + 16) + 2 * NS * 32 * 4;
+    if (int rc = ensure_lds(attn_bwd_fused_kernel<NS>, lds_f, &done_f, "attn_bwd_fused")) return rc;
+    hipLaunchKernelGGL(attn_bwd_fused_kernel<NS>, dim3(B * H), dim3(512), lds_f, s, qkv, out, dout, lse, dqkv, N, H);
+    VS_CHECK_LAUNCH("attn_bwd_fused");
+    return VITSSL_OK;
+  }
   static bool done_kv = false, done_q = false;
   const int lds_q = 2 * NS * 32 * ROWB;
   if (int rc = ensure_lds(attn_bwd_dq_kernel<NS>, lds_q, &done_q, "attn_bwd_dq")) return rc;
