@@ -171,6 +171,23 @@ def test_gemm_nt_epilogues(ops, M, N, K):
         assert rel_l2(outr, res + (acc + bias) * keep * scale) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(640, 256, 8192), (130, 64, 4160)])
+def test_gemm_nt_splitk_f32(ops, M, N, K):
+    """Few tiles + long contraction (DINO head dgrad shape): the fp32 epilogue runs as
+    split-K slices accumulating with atomics into a zeroed output; bias is added once."""
+    from vitssl_hip import _lib as L
+    torch.manual_seed(K)
+    A = bf(torch.randn(M, K) * 0.25)
+    B = bf(torch.randn(N, K) * 0.25)
+    bias = torch.randn(N)
+    acc = _ref_acc(A, B).float()
+    out32 = torch.full((M, N), 7.0, device=DEV)                # stale contents must not leak through
+    ops.gemm_nt(gpu(A), gpu(B), out32, L.EPI_F32, bias=gpu(bias))
+    assert rel_l2(out32, acc + bias) < 1e-5
+    ops.gemm_nt(gpu(A), gpu(B), out32, L.EPI_F32)
+    assert rel_l2(out32, acc) < 1e-5
+
+
 def test_gemm_nt_embed_epilogue(ops):
     from vitssl_hip import _lib as L
     torch.manual_seed(0)

@@ -69,7 +69,12 @@ struct NtParams {
   vitssl_embed_t embed;
   int tiles_m, tiles_n;
   int group_n;   // tile columns per raster group (their B panels stay L2-resident)
+  int k_chunk;   // split-K: K elements per blockIdx.y slice (0 = no split)
 };
+
+// internal epilogue: fp32 output accumulated with atomics by the split-K slices (out0 is
+// zeroed by the launcher; slice 0 adds the bias)
+constexpr int EPI_F32_SPLITK = 100;
 
 // XOR applied to the 16-byte chunk index of tile row r (source side for the DMA, and on
 // the fragment reads): BK=64 (128-B rows) chunk ^ ((r>>1)&7); BK=32 (64-B rows)
@@ -147,7 +152,8 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
   __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)a_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)b_bytes, 0x00020000);
 
-  const int nk = p.K / BK;
+  const int kb = p.k_chunk ? (int)blockIdx.y * p.k_chunk : 0;                       // this slice's K range
+  const int nk = (p.k_chunk ? min(p.K - kb, p.k_chunk) : p.K) / BK;
   const int swz = nt_swz<BK>(lane & 15);           // rows are 16*x + (lane&15)
   const int frag_row = lane & 15;
   const int kq = lane >> 4;
@@ -197,8 +203,8 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
   int n0 = 0, n0n = 0;
   if (!tile_of(0, m0, n0)) return;                 // workgroup-uniform
   int par = 0;                                     // LDS buffer of the stage consumed next
-  stage_tile<BK, BM, CFG::WAVES>(rsA, smem, m0, 0, p.K, wave, lane);
-  stage_tile<BK, BN, CFG::WAVES>(rsB, smem + CFG::A_BYTES, n0, 0, p.K, wave, lane);
+  stage_tile<BK, BM, CFG::WAVES>(rsA, smem, m0, kb, p.K, wave, lane);
+  stage_tile<BK, BN, CFG::WAVES>(rsB, smem + CFG::A_BYTES, n0, kb, p.K, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   for (int round = 0;; ++round) {
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
       const bool fetch = more || has_next;
       const long long sm = more ? m0 : m0n;
       const int sn = more ? n0 : n0n;
-      const int sk = more ? (t + 1) * BK : 0;
+      const int sk = kb + (more ? (t + 1) * BK : 0);
       if constexpr (BK == 64) {
         // spread the DMA over the step: A before the first MFMA cluster, B between the
         // two (a single 64-KiB burst right after the barrier queues in the TA)
@@ -306,7 +312,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
       const int nB = nA + 16;
       const bool okA = nA < p.N, okB = nB < p.N;
       f32x4 biasA = {0.f, 0.f, 0.f, 0.f}, biasB = biasA;
-      if (p.bias) {
+      if (p.bias && (EPI != EPI_F32_SPLITK || blockIdx.y == 0)) {
         if (okA) biasA = *(const f32x4*)(p.bias + nA);
         if (okB) biasB = *(const f32x4*)(p.bias + nB);
       }
@@ -391,6 +397,14 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
             w[h] = u32x2{pack_bf2(v[h][0], v[h][1]), pack_bf2(v[h][2], v[h][3])};
           }
           store_bf16_pair(rsOut0, i, jp, w[0], w[1]);
+        } else if constexpr (EPI == EPI_F32_SPLITK) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            if (!(okm && okn[h])) continue;
+            float* o = (float*)p.out0 + m * p.N + nn[h];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) unsafeAtomicAdd(o + r, v[h][r]);
+          }
         } else if constexpr (EPI == VITSSL_EPI_F32) {
   #pragma unroll
           for (int h = 0; h < 2; ++h)
@@ -450,7 +464,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
     // operations retire in issue order, so "at most <the stores of the last half> still in
     // flight" implies that DMA has landed, without waiting for the stores themselves.
     constexpr int TAIL = (EPI == VITSSL_EPI_GELU || EPI == VITSSL_EPI_F32 || EPI == VITSSL_EPI_RESID) ? 16
-                         : (EPI == VITSSL_EPI_EMBED ? 0 : 8);
+                         : ((EPI == VITSSL_EPI_EMBED || EPI == EPI_F32_SPLITK) ? 0 : 8);
     wait_vmcnt<TAIL>();
     m0 = m0n;
     n0 = n0n;
@@ -504,7 +518,8 @@ int launch_cfg(NtParams p, hipStream_t s) {
     const long long slots = (long long)cu_count() * CFG::WG_PER_CU;
     if (grid > slots) grid = slots;
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<EPI, CFG>), dim3((unsigned)grid), dim3(CFG::THREADS), CFG::LDS_BYTES, s, p);
+  const unsigned slices = p.k_chunk ? (unsigned)ceil_div64(p.K, p.k_chunk) : 1u;
+  hipLaunchKernelGGL((gemm_nt_kernel<EPI, CFG>), dim3((unsigned)grid, slices), dim3(CFG::THREADS), CFG::LDS_BYTES, s, p);
   VS_CHECK_LAUNCH("gemm_nt");
   return VITSSL_OK;
 }
@@ -519,8 +534,38 @@ int nt_tile_override() {
   return v;
 }
 
+// Split-K for fp32 outputs whose grid cannot fill the chip but whose contraction is long
+// (DINO head: dX[640,256] = dY[640,65536] . W[65536,256] is 6 SMALL tiles x 2048 K-steps:
+// 483 us on 6 CUs).  The K range is cut into slices that accumulate with fp32 atomics into a
+// zeroed output; enough slices to put ~2 workgroups on every CU.
+int launch_splitk_f32(NtParams p, hipStream_t s, bool* done) {
+  *done = false;
+  const long long tiles = ceil_div64(p.M, NtSmall::BM) * ceil_div64(p.N, NtSmall::BN);
+  if (tiles >= 64 || p.K < 4096) return VITSSL_OK;
+  long long slices = (2LL * cu_count() + tiles - 1) / tiles;
+  const long long max_slices = p.K / 512;            // at least 16 K-steps of 32 per slice
+  if (slices > max_slices) slices = max_slices;
+  if (slices < 2) return VITSSL_OK;
+  long long chunk = ceil_div64(ceil_div64(p.K, slices), 64) * 64;
+  p.k_chunk = (int)chunk;
+  hipError_t e = hipMemsetAsync(p.out0, 0, (size_t)p.M * p.N * sizeof(float), s);
+  if (e != hipSuccess) {
+    vitssl_set_error("gemm_nt: split-K memset failed: %s", hipGetErrorString(e));
+    return VITSSL_ERR_LAUNCH;
+  }
+  *done = true;
+  return launch_cfg<EPI_F32_SPLITK, NtSmall>(p, s);
+}
+
 template <int EPI>
 int launch_nt(const NtParams& p, hipStream_t s) {
+  if constexpr (EPI == VITSSL_EPI_F32) {
+    if (!p.colsum) {
+      bool done = false;
+      const int rc = launch_splitk_f32(p, s, &done);
+      if (rc != VITSSL_OK || done) return rc;
+    }
+  }
   const int mode = nt_tile_override();
   if (mode == 1) return launch_cfg<EPI, NtBig>(p, s);
   if (mode == 2) return launch_cfg<EPI, NtSmall>(p, s);
@@ -556,6 +601,7 @@ extern "C" int vitssl_gemm_bf16_nt(const vitssl_gemm_t* g, void* stream) {
   p.drop_on = p.dk.thr != 0;
   p.embed = g->embed;
   p.tiles_m = p.tiles_n = p.group_n = 0;   // set per tile configuration in launch_cfg
+  p.k_chunk = 0;
   hipStream_t s = (hipStream_t)stream;
   switch (g->epilogue) {
     case VITSSL_EPI_BF16: return launch_nt<VITSSL_EPI_BF16>(p, s);
