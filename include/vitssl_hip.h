@@ -173,6 +173,18 @@ int vitssl_colsum_bf16(const void* x_bf16, float* out, int64_t rows, int cols, v
 int vitssl_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
 /* dst_t bf16 [C,R] = transpose(src f32 [R,C]) ; dst bf16 [R,C] = src (either may be NULL) */
 int vitssl_cast_transpose_bf16(const float* src, void* dst, void* dst_t, int R, int C, void* stream);
+/* The same for a whole table of weights in ONE launch (the per-step bf16 refresh of every
+ * nn.Linear weight that torch.autocast performs implicitly in the reference's trainers,
+ * utils/trainers/simmim_trainer.py:37, dino_trainer.py:86).  `jobs` and `tile_start` live in
+ * DEVICE memory: tile_start[njobs + 1] is the exclusive prefix sum of ceil(R/64)*ceil(C/64). */
+typedef struct {
+  const float* src; /* f32 [R, C] */
+  void* dst;        /* bf16 [R, C] or NULL */
+  void* dst_t;      /* bf16 [C, R] or NULL */
+  int R, C;
+} vitssl_cast_job_t;
+int vitssl_cast_transpose_batch(const vitssl_cast_job_t* jobs, const int* tile_start, int njobs, int total_tiles,
+                                void* stream);
 /* torch.optim.AdamW step over a flat fp32 buffer (utils/train_utils.py:25-29). step is 1-based;
  * g is multiplied by gscale first (1/world_size for DP averaging). */
 int vitssl_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

@@ -414,6 +414,21 @@ def test_casts(ops):
         dst_t = torch.empty(Cn, R, dtype=torch.bfloat16, device=DEV)
         ops.cast_transpose_bf16(gpu(src), dst, dst_t)
         assert torch.equal(dst.cpu(), bf(src)) and torch.equal(dst_t.cpu(), bf(src).t())
+    # the whole table in one launch (ragged shapes, optional outputs), twice through one plan
+    shapes = ((768, 2304), (100, 37), (65, 64), (1, 5), (192, 128))
+    srcs = [gpu(torch.randn(R, Cn)) for R, Cn in shapes]
+    dsts = [torch.empty(R, Cn, dtype=torch.bfloat16, device=DEV) if i != 1 else None for i, (R, Cn) in enumerate(shapes)]
+    dts = [torch.empty(Cn, R, dtype=torch.bfloat16, device=DEV) if i != 2 else None for i, (R, Cn) in enumerate(shapes)]
+    plan = ops.CastPlan()
+    for rep in range(2):
+        for s_ in srcs:
+            s_.add_(1.0)
+        plan.run(list(zip(srcs, dsts, dts)))
+        for s_, d_, t_ in zip(srcs, dsts, dts):
+            if d_ is not None:
+                assert torch.equal(d_.cpu(), bf(s_.cpu()))
+            if t_ is not None:
+                assert torch.equal(t_.cpu(), bf(s_.cpu()).t())
     v = torch.randn(1003)
     d = torch.empty(1003, dtype=torch.bfloat16, device=DEV)
     ops.cast_bf16(gpu(v), d)

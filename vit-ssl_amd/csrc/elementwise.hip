@@ -238,6 +238,43 @@ __global__ void cast_transpose_kernel(const float* __restrict__ src, bf16_t* __r
   }
 }
 
+// every weight of a parameter store in one launch: block -> (job, 64x64 tile) by binary
+// search in the tile prefix sum
+__global__ void cast_transpose_batch_kernel(const vitssl_cast_job_t* __restrict__ jobs, const int* __restrict__ tile_start,
+                                            int njobs) {
+  __shared__ bf16_t tile[64][66];
+  const int b = blockIdx.x;
+  int lo = 0, hi = njobs;              // tile_start[lo] <= b < tile_start[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (tile_start[mid] <= b) lo = mid; else hi = mid;
+  }
+  const vitssl_cast_job_t j = jobs[lo];
+  const int t = b - tile_start[lo];
+  const int tx_n = (j.C + 63) >> 6;
+  const int r0 = (t / tx_n) * 64, c0 = (t % tx_n) * 64;
+  const int R = j.R, C = j.C;
+  bf16_t* dst = (bf16_t*)j.dst;
+  bf16_t* dst_t = (bf16_t*)j.dst_t;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int rr = ty; rr < 64; rr += 4) {
+    const int r = r0 + rr, c = c0 + tx;
+    bf16_t h = 0;
+    if (r < R && c < C) {
+      h = f2bf(j.src[(long long)r * C + c]);
+      if (dst) dst[(long long)r * C + c] = h;
+    }
+    tile[rr][tx] = h;
+  }
+  __syncthreads();
+  if (dst_t) {
+    for (int cc = ty; cc < 64; cc += 4) {
+      const int c = c0 + cc, r = r0 + tx;
+      if (c < C && r < R) dst_t[(long long)c * R + r] = tile[tx][cc];
+    }
+  }
+}
+
 // ------------------------------------------------------------------ optimizer / EMA
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                              long long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
@@ -432,6 +469,15 @@ extern "C" int vitssl_cast_transpose_bf16(const float* src, void* dst, void* dst
   hipLaunchKernelGGL(cast_transpose_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(EW_THREADS), 0, (hipStream_t)stream, src,
                      (bf16_t*)dst, (bf16_t*)dst_t, R, C);
   VS_CHECK_LAUNCH("cast_transpose");
+  return VITSSL_OK;
+}
+
+extern "C" int vitssl_cast_transpose_batch(const vitssl_cast_job_t* jobs, const int* tile_start, int njobs, int total_tiles,
+                                           void* stream) {
+  VS_CHECK_ARG(jobs && tile_start && njobs > 0 && total_tiles > 0, "cast_transpose_batch: bad args");
+  hipLaunchKernelGGL(cast_transpose_batch_kernel, dim3(total_tiles), dim3(EW_THREADS), 0, (hipStream_t)stream, jobs, tile_start,
+                     njobs);
+  VS_CHECK_LAUNCH("cast_transpose_batch");
   return VITSSL_OK;
 }
 

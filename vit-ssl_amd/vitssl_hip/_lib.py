@@ -55,6 +55,7 @@ PROTOTYPES = {
     "vitssl_colsum_bf16": [_vp, _vp, _i64, _i, _vp],
     "vitssl_cast_bf16": [_vp, _vp, _i64, _vp],
     "vitssl_cast_transpose_bf16": [_vp, _vp, _vp, _i, _i, _vp],
+    "vitssl_cast_transpose_batch": [_vp, _vp, _i, _i, _vp],
     "vitssl_adamw": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _vp],
     "vitssl_ema": [_vp, _vp, _i64, _f, _vp],
     "vitssl_rownorm_fwd": [_vp, _vp, _vp, _i64, _i, _vp],

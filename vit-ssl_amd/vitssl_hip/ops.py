@@ -253,6 +253,41 @@ def cast_transpose_bf16(src, dst, dst_t):
          R, Cn, _stream())
 
 
+class CastPlan:
+    """Device-resident job table for `cast_transpose_batch`: built once per set of
+    (source, destination) pointers, re-uploaded only when a pointer or shape changes."""
+
+    def __init__(self):
+        self.key = None
+        self.jobs_dev = None
+        self.starts_dev = None
+        self.njobs = 0
+        self.total = 0
+        self.keep = None
+
+    def run(self, jobs):
+        """jobs: list of (src f32 [R,C], dst bf16 [R,C] | None, dst_t bf16 [C,R] | None)."""
+        import numpy as np
+        key = tuple((s.data_ptr(), 0 if d is None else d.data_ptr(), 0 if t is None else t.data_ptr(), s.shape[0], s.shape[1])
+                    for s, d, t in jobs)
+        if key != self.key:
+            for s, d, t in jobs:
+                R, Cn = s.shape
+                _chk(s, F32, "src"); _opt(d, BF16, "dst", (R, Cn)); _opt(t, BF16, "dst_t", (Cn, R))
+            dev = jobs[0][0].device
+            rec = np.zeros(len(jobs), dtype=np.dtype([("src", "<u8"), ("dst", "<u8"), ("dst_t", "<u8"), ("R", "<i4"), ("C", "<i4")]))
+            starts = np.zeros(len(jobs) + 1, dtype=np.int32)
+            for i, k in enumerate(key):
+                rec[i] = k
+                starts[i + 1] = starts[i] + ((k[3] + 63) // 64) * ((k[4] + 63) // 64)
+            self.jobs_dev = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
+            self.starts_dev = torch.from_numpy(starts).to(dev)
+            self.njobs, self.total, self.key = len(jobs), int(starts[-1]), key
+        self.keep = jobs        # the sources must outlive the launch
+        call("vitssl_cast_transpose_batch", C.c_void_p(self.jobs_dev.data_ptr()), C.c_void_p(self.starts_dev.data_ptr()),
+             self.njobs, self.total, _stream())
+
+
 def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step, gscale=1.0):
     n = p.numel()
     call("vitssl_adamw", _chk(p, F32, "p"), _chk(g, F32, "g", p.shape), _chk(m, F32, "m", p.shape), _chk(v, F32, "v", p.shape),
