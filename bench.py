@@ -118,11 +118,12 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
     import torch.distributed as dist
+    dev = torch.device("cuda:0" if args.share_gpu else f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)                               # bind the GPU before RCCL sees the process
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(args.backend, rank=rank, world_size=world)
-    dev = torch.device("cuda:0" if args.share_gpu else f"cuda:{local_rank}")
-    torch.cuda.set_device(dev)
+        kw = {"device_id": dev} if args.backend == "nccl" else {}
+        dist.init_process_group(args.backend, rank=rank, world_size=world, **kw)
 
     from vit_core.ssl.simmim import SimMIMViT
     from vitssl_hip import ops
