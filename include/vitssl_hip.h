@@ -132,7 +132,8 @@ int vitssl_gemm_bf16_tn(const void* A, const void* B, float* C, int64_t M, int N
  * dh in {32, 64, 128}; scale = 1/sqrt(dh). */
 int vitssl_attn_fwd(const void* qkv, void* out, float* lse, float* probs, int B, int N, int H, int dh,
                     void* stream);
-/* delta_ws: f32 [B,H,N] scratch (rowsum(dO*O)); dqkv bf16 [B,N,3,H,dh] fully overwritten. */
+/* delta_ws: f32 [B,H,N] scratch for rowsum(dO*O) (used by the two-launch variant only; the default
+ * one-launch backward keeps delta in LDS); dqkv bf16 [B,N,3,H,dh] fully overwritten. */
 int vitssl_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                     float* delta_ws, int B, int N, int H, int dh, void* stream);
 
