@@ -6,7 +6,6 @@ Tolerances: bf16 outputs are compared after the reference is rounded the same wa
 differences); fp32 outputs to 1e-5..1e-4 relative; integer/byte/gather work bit-exact."""
 import math
 
-import numpy as np
 import pytest
 import torch
 

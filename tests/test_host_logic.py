@@ -1,14 +1,13 @@
 """Host-side logic that needs no GPU: mask stream vs the oracle, index bookkeeping,
 state_dict key compatibility with the reference, model_builder dispatch / checkpoint
 remapping, schedulers, config helpers."""
-import math
 import os
 
 import numpy as np
 import pytest
 import torch
 
-from _util import load_golden, split_prefix, t
+from _util import load_golden, split_prefix
 from oracle import vit_oracle as O
 
 

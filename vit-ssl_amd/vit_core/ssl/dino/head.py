@@ -7,7 +7,7 @@ from torch.autograd import Function
 from torch.nn.utils.parametrizations import weight_norm
 
 from ... import _runtime as R
-from ..._runtime import BF16, F32, L, ops
+from ..._runtime import BF16, F32, ops
 from ._head_runtime import HeadRuntime
 
 

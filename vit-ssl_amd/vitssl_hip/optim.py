@@ -1,8 +1,6 @@
 """Flat fused AdamW: one HIP kernel over the model's flat parameter buffer
 (torch.optim.AdamW semantics; reference builds AdamW reflectively at
 utils/train_utils.py:25-29 with configs/base/training.yaml:10-15)."""
-from typing import Optional
-
 import torch
 
 from . import ops
