@@ -155,8 +155,13 @@ int vitssl_scatter_cls_f32(const float* gcls, float* g, int B, int T, int D, voi
 /* Patch-embedding backward glue: from dtok f32 [B*T_out, D] produce the bf16 operand
  * of the projection wgrad (masked rows zeroed, CLS rows dropped) and accumulate
  * d(pos) [T_out, D], d(mask_token) [D], d(bias) [D], d(cls_token) [D]. */
+int64_t vitssl_embed_bwd_workspace_floats(int B, int tokens, int tok_offset, int D);
+/* workspace (may be NULL = atomics only): vitssl_embed_bwd_workspace_floats() floats of scratch
+ * through which the single-row accumulators d(mask_token) / d(bias) are reduced without
+ * thousands of colliding atomics. */
 int vitssl_embed_bwd(const float* dtok, const uint8_t* mask, void* dproj_bf16, float* dpos, float* dmask_token,
-                     float* dbias, float* dcls, int B, int tokens, int tok_offset, int D, void* stream);
+                     float* dbias, float* dcls, int B, int tokens, int tok_offset, int D, float* workspace,
+                     int64_t workspace_floats, void* stream);
 
 /* ---- losses ------------------------------------------------------------------- */
 /* nn.L1Loss(mean) (configs/simmim/training.yaml:2-5): loss_sum += sum|p-t| (caller zeroes,

@@ -107,7 +107,8 @@ __global__ void scatter_cls_kernel(const float* __restrict__ gcls, float* __rest
 // grid = (T_out, bsplits); thread = 4 columns
 __global__ void embed_bwd_kernel(const float* __restrict__ dtok, const unsigned char* __restrict__ mask,
                                  bf16_t* __restrict__ dproj, float* __restrict__ dpos, float* __restrict__ dmask_token,
-                                 float* __restrict__ dbias, float* __restrict__ dcls, int B, int tokens, int tok_offset, int D) {
+                                 float* __restrict__ dbias, float* __restrict__ dcls, int B, int tokens, int tok_offset, int D,
+                                 float* __restrict__ ws) {
   const int t = blockIdx.x;
   const int T_out = tokens + tok_offset;
   const int per = (B + gridDim.y - 1) / gridDim.y;
@@ -144,12 +145,41 @@ __global__ void embed_bwd_kernel(const float* __restrict__ dtok, const unsigned 
     for (int r = 0; r < 4; ++r) {
       if (dpos) atomicAdd(dpos + (long long)t * D + c + r, pos[r]);
       if (t >= tok_offset) {
+        if (ws) continue;   // single-row accumulators go through the workspace (below)
         if (dmask_token) atomicAdd(dmask_token + c + r, mt[r]);
         if (dbias) atomicAdd(dbias + c + r, bias[r]);
       } else if (dcls) {
         atomicAdd(dcls + c + r, pos[r]);
       }
     }
+    if (ws && t >= tok_offset) {
+      // d(mask_token) and d(bias) are single rows fed by EVERY block (~2000 adders per
+      // address: the atomic path ran 250-420 us); each block parks its partials instead and
+      // embed_bwd_reduce_kernel sums them
+      float* slot = ws + ((long long)(blockIdx.y * gridDim.x + t) * 2) * D + c;
+      *(f32x4*)slot = mt;
+      *(f32x4*)(slot + D) = bias;
+    }
+  }
+}
+
+// column sums of the parked partials: ws [nblk][2][D] -> dmask_token[D], dbias[D]; rows of
+// blocks with t < tok_offset were never written and are skipped
+__global__ void embed_bwd_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dmask_token, float* __restrict__ dbias,
+                                        int T_out, int tok_offset, int nblk, int D) {
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (c >= D) return;
+  f32x4 mt = {0.f, 0.f, 0.f, 0.f}, bias = mt;
+  for (int i = blockIdx.y; i < nblk; i += gridDim.y) {
+    if (i % T_out < tok_offset) continue;
+    const float* slot = ws + (long long)i * 2 * D + c;
+    mt += *(const f32x4*)slot;
+    bias += *(const f32x4*)(slot + D);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (dmask_token) atomicAdd(dmask_token + c + r, mt[r]);
+    if (dbias) atomicAdd(dbias + c + r, bias[r]);
   }
 }
 
@@ -411,21 +441,41 @@ extern "C" int vitssl_scatter_cls_f32(const float* gcls, float* g, int B, int T,
   return VITSSL_OK;
 }
 
-extern "C" int vitssl_embed_bwd(const float* dtok, const uint8_t* mask, void* dproj_bf16, float* dpos, float* dmask_token,
-                                float* dbias, float* dcls, int B, int tokens, int tok_offset, int D, void* stream) {
-  VS_CHECK_ARG(dtok && dproj_bf16 && B > 0 && tokens > 0 && D > 0 && D % 4 == 0, "embed_bwd: bad args");
-  VS_CHECK_ARG(tok_offset == 0 || tok_offset == 1, "embed_bwd: tok_offset must be 0 or 1");
-  VS_CHECK_ARG(!mask || dmask_token, "embed_bwd: mask without dmask_token");
-  const int T_out = tokens + tok_offset;
-  // few blocks along the batch axis: every block ends with D atomics per accumulator row
-  // (dmask_token / dbias are single rows: contention grows with the block count)
+static int embed_bwd_splits(int B, int T_out) {
   int bs = 2048 / T_out;
   if (bs < 1) bs = 1;
   if (bs > B) bs = B;
   if (bs > 16) bs = 16;
+  return bs;
+}
+
+extern "C" int64_t vitssl_embed_bwd_workspace_floats(int B, int tokens, int tok_offset, int D) {
+  if (B <= 0 || tokens <= 0 || D <= 0) return 0;
+  const int T_out = tokens + tok_offset;
+  return (int64_t)embed_bwd_splits(B, T_out) * T_out * 2 * D;
+}
+
+extern "C" int vitssl_embed_bwd(const float* dtok, const uint8_t* mask, void* dproj_bf16, float* dpos, float* dmask_token,
+                                float* dbias, float* dcls, int B, int tokens, int tok_offset, int D, float* workspace,
+                                int64_t workspace_floats, void* stream) {
+  VS_CHECK_ARG(dtok && dproj_bf16 && B > 0 && tokens > 0 && D > 0 && D % 4 == 0, "embed_bwd: bad args");
+  VS_CHECK_ARG(tok_offset == 0 || tok_offset == 1, "embed_bwd: tok_offset must be 0 or 1");
+  VS_CHECK_ARG(!mask || dmask_token, "embed_bwd: mask without dmask_token");
+  const int T_out = tokens + tok_offset;
+  const int bs = embed_bwd_splits(B, T_out);
+  const int64_t need = (int64_t)bs * T_out * 2 * D;
+  VS_CHECK_ARG(!workspace || workspace_floats >= need, "embed_bwd: workspace of %lld floats, need %lld", (long long)workspace_floats,
+               (long long)need);
+  float* ws = (dmask_token || dbias) ? workspace : nullptr;   // NULL workspace = atomics fallback
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(T_out, bs), dim3(EW_THREADS), 0, (hipStream_t)stream, dtok, mask, (bf16_t*)dproj_bf16,
-                     dpos, dmask_token, dbias, dcls, B, tokens, tok_offset, D);
+                     dpos, dmask_token, dbias, dcls, B, tokens, tok_offset, D, ws);
   VS_CHECK_LAUNCH("embed_bwd");
+  if (ws) {
+    const int nblk = bs * T_out;
+    hipLaunchKernelGGL(embed_bwd_reduce_kernel, dim3((D / 4 + 63) / 64, 16), dim3(64), 0, (hipStream_t)stream, ws, dmask_token, dbias,
+                       T_out, tok_offset, nblk, D);
+    VS_CHECK_LAUNCH("embed_bwd_reduce");
+  }
   return VITSSL_OK;
 }
 

@@ -49,7 +49,7 @@ PROTOTYPES = {
     "vitssl_scatter_rows_f32": [_vp, _vp, _vp, _i64, _i, _vp],
     "vitssl_gather_cls_f32": [_vp, _vp, _i, _i, _i, _vp],
     "vitssl_scatter_cls_f32": [_vp, _vp, _i, _i, _i, _vp],
-    "vitssl_embed_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "vitssl_embed_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i64, _vp],
     "vitssl_l1_loss": [_vp, _vp, _vp, _vp, _f, _i64, _vp],
     "vitssl_cross_entropy": [_vp, _vp, _vp, _vp, _f, _i, _i, _vp],
     "vitssl_colsum_bf16": [_vp, _vp, _i64, _i, _vp],
@@ -92,6 +92,8 @@ def lib():
     l.vitssl_version.argtypes = []
     l.vitssl_gemm_tn_workspace_floats.restype = C.c_int64
     l.vitssl_gemm_tn_workspace_floats.argtypes = [C.c_int64, C.c_int, C.c_int]
+    l.vitssl_embed_bwd_workspace_floats.restype = C.c_int64
+    l.vitssl_embed_bwd_workspace_floats.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     for name, args in PROTOTYPES.items():
         fn = getattr(l, name)  # AttributeError if the symbol is missing
         fn.restype = C.c_int

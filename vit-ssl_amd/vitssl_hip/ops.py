@@ -220,10 +220,12 @@ def scatter_cls_f32(gcls, g, B, T, D):
 
 def embed_bwd(dtok, mask, dproj, dpos, dmask_token, dbias, dcls, B, tokens, tok_offset, D):
     T_out = tokens + tok_offset
+    wsn = int(L.lib().vitssl_embed_bwd_workspace_floats(B, tokens, tok_offset, D))
+    ws = _tn_workspace(dtok.device, wsn)       # shared scratch: launches on one stream are ordered
     call("vitssl_embed_bwd", _chk(dtok, F32, "dtok", (B * T_out, D)), _opt(mask, torch.uint8, "mask", (B * tokens,)),
          _chk(dproj, BF16, "dproj", (B * tokens, D)), _opt(dpos, F32, "dpos", (T_out, D)),
          _opt(dmask_token, F32, "dmask_token", (D,)), _opt(dbias, F32, "dbias", (D,)), _opt(dcls, F32, "dcls", (D,)),
-         B, tokens, tok_offset, D, _stream())
+         B, tokens, tok_offset, D, C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
 
 
 def l1_loss(pred, target, loss_sum, dpred=None, gscale=0.0):
