@@ -170,6 +170,7 @@ __global__ void embed_bwd_reduce_kernel(const float* __restrict__ ws, float* __r
   const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (c >= D) return;
   f32x4 mt = {0.f, 0.f, 0.f, 0.f}, bias = mt;
+#pragma unroll 4
   for (int i = blockIdx.y; i < nblk; i += gridDim.y) {
     if (i % T_out < tok_offset) continue;
     const float* slot = ws + (long long)i * 2 * D + c;
@@ -472,7 +473,7 @@ extern "C" int vitssl_embed_bwd(const float* dtok, const uint8_t* mask, void* dp
   VS_CHECK_LAUNCH("embed_bwd");
   if (ws) {
     const int nblk = bs * T_out;
-    hipLaunchKernelGGL(embed_bwd_reduce_kernel, dim3((D / 4 + 63) / 64, 16), dim3(64), 0, (hipStream_t)stream, ws, dmask_token, dbias,
+    hipLaunchKernelGGL(embed_bwd_reduce_kernel, dim3((D / 4 + 63) / 64, 128), dim3(64), 0, (hipStream_t)stream, ws, dmask_token, dbias,
                        T_out, tok_offset, nblk, D);
     VS_CHECK_LAUNCH("embed_bwd_reduce");
   }

@@ -19,7 +19,7 @@
 // k-tile t (A before the first 32-MFMA cluster, B before the second) and retired
 // (vmcnt(0) + barrier) after them.
 //
-// Optional persistent mode (VITSSL_NT_PERSIST=1, off by default -- see launch_cfg): the grid
+// Persistent mode (short contractions only by default -- see launch_cfg): the grid
 // is one workgroup per CU slot, each workgroup walks tiles b, b + G, ... and the first stage
 // of the NEXT tile is issued during the last K-step of the current one, so it lands behind
 // the epilogue.  With one tile per workgroup the same loop simply runs once.
@@ -503,15 +503,17 @@ int launch_cfg(NtParams p, hipStream_t s) {
   else if (p.tiles_n % 4 == 0) p.group_n = 4;
   else if (p.tiles_n % 3 == 0) p.group_n = 3;
   else p.group_n = want < 4 ? want : 4;
-  // VITSSL_NT_PERSIST=1: persistent workgroups (developer knob).  Measured on MI355X: back to
-  // back launches of one shape gain 1-4 % (tools/bench_gemm.py), but inside the training step
-  // (bench.py, same box, alternating runs) the NT family takes 23.12 ms either way and the
-  // whole step is 0.2-0.5 ms SLOWER, so the default stays one tile per workgroup.
-  static int persist = -1;
-  if (persist < 0) {
+  // Persistent workgroups.  Measured on MI355X (bench.py, same box, alternating runs): with
+  // K = 768 / 3072 (ViT-B) the NT family takes 23.12 ms per step either way and the whole step
+  // is 0.2-0.5 ms slower persistent; with K = 384 (ViT-S: 6 K-steps per tile, the fixed
+  // per-tile cost dominates) the step drops 21.75 -> 20.83 ms.  Default: persistent for
+  // K <= 512 only; VITSSL_NT_PERSIST=0/1 forces it (developer knob).
+  static int knob = -2;
+  if (knob == -2) {
     const char* e = getenv("VITSSL_NT_PERSIST");
-    persist = e ? atoi(e) : 0;
+    knob = e ? atoi(e) : -1;
   }
+  const bool persist = knob >= 0 ? knob != 0 : p.K <= 512;
   const long long ntiles = (long long)p.tiles_m * p.tiles_n;
   long long grid = ntiles;
   if (persist) {
@@ -573,6 +575,8 @@ int launch_nt(const NtParams& p, hipStream_t s) {
   // shape, heavy epilogues included; it only pays for grids too small to fill the chip.
   const long long big_tiles = ceil_div64(p.M, 256) * ceil_div64(p.N, 256);
   if (big_tiles < 64) return launch_cfg<EPI, NtSmall>(p, s);
+  // (N = 384, ViT-S: three exact 128-wide SMALL columns instead of two 256-wide ones with the
+  // second half empty were measured too: 21.1 vs 20.9 ms per step, not worth it.)
   return launch_cfg<EPI, NtBig>(p, s);
 }
 
