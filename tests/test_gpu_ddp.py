@@ -86,3 +86,55 @@ def test_two_ranks_equal_single_process(tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def _rccl_worker(port, out_dir):
+    """world_size 1 over the real `nccl` (= RCCL) backend: the communicator is created with
+    device_id, and the reducer's bucketed side-stream all-reduce runs through RCCL kernels.
+    A one-rank sum is the identity, so the step must equal a reducer-less step."""
+    for p in (ROOT, os.path.join(ROOT, "vit-ssl_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        from vit_core.ssl.simmim.masking import draw_mask
+        from vitssl_hip.engine import GradReducer
+        from vitssl_hip.optim import FusedAdamW
+        g = torch.Generator().manual_seed(3)
+        x = torch.rand(8, 3, 32, 32, generator=g).to(dev)
+        torch.manual_seed(11)
+        mask = draw_mask(8, 16, 0.6)
+        outs = []
+        for use_reducer in (True, False):
+            model = _build(dev)
+            store = model.flat_store()
+            red = None
+            if use_reducer:
+                dist.broadcast(store.flat, 0)
+                red = GradReducer(store.gflat, bucket_mb=0.5)
+                red.world = 2                 # force the collective path; one rank's sum = identity
+            opt = FusedAdamW(store, lr=1e-3, weight_decay=1e-3)
+            loss = model.train_step(x, opt, red, mask_cpu=mask)
+            dist.barrier()
+            torch.cuda.synchronize()
+            if use_reducer:
+                assert len(red.launched) >= 2
+            outs.append((float(loss), store.gflat.clone()))
+        from _util import rel_l2
+        assert abs(outs[0][0] - outs[1][0]) < 1e-6
+        # all-reduce over one rank changes nothing (float atomics in the bias / LayerNorm
+        # gradient sums make two runs differ in the last bits, hence not torch.equal)
+        assert rel_l2(outs[0][1], outs[1][1]) < 1e-5
+        open(os.path.join(out_dir, "ok_rccl"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_single_rank_side_stream_allreduce(tmp_path):
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), str(tmp_path)))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0 and os.path.exists(tmp_path / "ok_rccl")
