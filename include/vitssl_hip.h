@@ -221,6 +221,30 @@ int vitssl_colsum_f32(const float* x, float* out, int64_t rows, int cols, void* 
 /* center = m center + (1-m) colsum * inv_rows   (all-reduce colsum first under data parallelism) */
 int vitssl_center_ema(float* center, const float* colsum, int K, float momentum, float inv_rows, void* stream);
 
+/* ---- DINO multi-crop input pipeline -------------------------------
+ * Replaces, per view, the torchvision transform list that data/datasets.py:80-123
+ * (STL10DINODataset._get_dino_views) applies on the CPU with PIL images:
+ * configs/dino/globals.yaml / locals.yaml = RandomResizedCrop, RandomHorizontalFlip,
+ * ColorJitter, [RandomGrayscale], GaussianBlur(7), ToTensor (built by utils/train_utils.py:54-68).
+ * The random parameters are drawn on the host (vit-ssl_amd/data/multicrop.py) and handed over
+ * as device arrays:
+ *   iparams int32 [B, 11] = top, left, h, w, flip, order[4] (0 brightness 1 contrast
+ *                           2 saturation 3 hue), gray, hue_shift (uint8 added to H, wraps)
+ *   fparams f32   [B, 10] = brightness, contrast, saturation factors, k1d[7] (normalised
+ *                           Gaussian taps of this image's sigma)
+ * Results are bit-identical to Pillow's uint8 arithmetic (oracle/augment_oracle.py). */
+/* src u8 [B,H,W,3] -> dst u8 [B,S,S,3]: crop box, Pillow BILINEAR resize (horizontal then
+ * vertical 8bpc pass), optional horizontal flip.  tmp: u8 scratch [B,H,S,3]. */
+int vitssl_aug_resized_crop_u8(const uint8_t* src, const int32_t* iparams, uint8_t* tmp, uint8_t* dst, int B, int H,
+                               int W, int S, void* stream);
+/* in place on u8 [B,S,S,3]: the four ColorJitter ops in the sampled order, then grayscale if
+ * iparams[9]; S*S*3 <= 150 KiB (S <= 224) */
+int vitssl_aug_color_u8(uint8_t* img, const int32_t* iparams, const float* fparams, int B, int S, void* stream);
+/* u8 [B,S,S,3] -> f32 [B,3,S,S]: ksize x ksize Gaussian blur (reflect padding, float32, rounded
+ * back to uint8) followed by ToTensor (/255) */
+int vitssl_aug_blur_to_tensor(const uint8_t* img, const float* fparams, float* out, int B, int S, int ksize,
+                              void* stream);
+
 #ifdef __cplusplus
 }
 #endif

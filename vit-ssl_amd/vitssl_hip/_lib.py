@@ -56,6 +56,9 @@ PROTOTYPES = {
     "vitssl_cast_bf16": [_vp, _vp, _i64, _vp],
     "vitssl_cast_transpose_bf16": [_vp, _vp, _vp, _i, _i, _vp],
     "vitssl_cast_transpose_batch": [_vp, _vp, _i, _i, _vp],
+    "vitssl_aug_resized_crop_u8": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "vitssl_aug_color_u8": [_vp, _vp, _vp, _i, _i, _vp],
+    "vitssl_aug_blur_to_tensor": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "vitssl_adamw": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _vp],
     "vitssl_ema": [_vp, _vp, _i64, _f, _vp],
     "vitssl_rownorm_fwd": [_vp, _vp, _vp, _i64, _i, _vp],

@@ -338,3 +338,28 @@ def colsum_f32(x, out):
 def center_ema(center, colsum, momentum, inv_rows):
     K = colsum.numel()
     call("vitssl_center_ema", _chk(center, F32, "center"), _chk(colsum, F32, "colsum"), K, float(momentum), float(inv_rows), _stream())
+
+
+# ---- DINO multi-crop input pipeline (data/datasets.py:80-123) -------------------------------
+AUG_IP, AUG_FP = 11, 10
+
+
+def aug_resized_crop_u8(src, iparams, tmp, dst):
+    B, H, W, Cc = src.shape
+    S = dst.shape[1]
+    if Cc != 3:
+        raise L.VitsslError(f"aug_resized_crop: expected channel-last RGB [B,H,W,3], got {tuple(src.shape)}")
+    call("vitssl_aug_resized_crop_u8", _chk(src, torch.uint8, "src"), _chk(iparams, torch.int32, "iparams", (B, AUG_IP)),
+         _chk(tmp, torch.uint8, "tmp", (B, H, S, 3)), _chk(dst, torch.uint8, "dst", (B, S, S, 3)), B, H, W, S, _stream())
+
+
+def aug_color_u8(img, iparams, fparams):
+    B, S = img.shape[0], img.shape[1]
+    call("vitssl_aug_color_u8", _chk(img, torch.uint8, "img", (B, S, S, 3)), _chk(iparams, torch.int32, "iparams", (B, AUG_IP)),
+         _chk(fparams, F32, "fparams", (B, AUG_FP)), B, S, _stream())
+
+
+def aug_blur_to_tensor(img, fparams, out, ksize=7):
+    B, S = img.shape[0], img.shape[1]
+    call("vitssl_aug_blur_to_tensor", _chk(img, torch.uint8, "img", (B, S, S, 3)), _chk(fparams, F32, "fparams", (B, AUG_FP)),
+         _chk(out, F32, "out", (B, 3, S, S)), B, S, ksize, _stream())
