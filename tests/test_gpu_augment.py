@@ -104,12 +104,23 @@ def test_view_list_layout_and_statistics(ops):
     assert [tuple(v.shape) for v in views] == [(B, 3, 224, 224)] * 2 + [(B, 3, 96, 96)] * 4
     for v in views:
         assert v.dtype == torch.float32 and float(v.min()) >= 0.0 and float(v.max()) <= 1.0
+    from data.multicrop import pack_params, params_as_list, sample_batch_params
     gen = torch.Generator().manual_seed(1)
-    draws = [sample_view_params(gs, 96, 96, gen) for _ in range(2000)]
-    assert 0.45 < np.mean([d["flip"] for d in draws]) < 0.55
-    assert 0.16 < np.mean([d["gray"] for d in draws]) < 0.24
-    areas = np.array([d["h"] * d["w"] for d in draws]) / (96 * 96)
-    assert areas.min() >= 0.45 and areas.max() <= 1.0 + 1e-9
+    arrs = sample_batch_params(gs, 96, 96, 2000, gen)
+    ip_a, fp_a = pack_params(arrs, 7)                      # array path == per-view path, bit for bit
+    ip_l, fp_l = pack_params(params_as_list(arrs), 7)
+    assert np.array_equal(ip_a, ip_l) and np.array_equal(fp_a, fp_l)
+    for draws in ([sample_view_params(gs, 96, 96, gen) for _ in range(2000)], params_as_list(arrs)):
+        assert 0.45 < np.mean([d["flip"] for d in draws]) < 0.55
+        assert 0.16 < np.mean([d["gray"] for d in draws]) < 0.24
+        areas = np.array([d["h"] * d["w"] for d in draws]) / (96 * 96)
+        assert areas.min() >= 0.45 and areas.max() <= 1.0 + 1e-9
+        assert 0.66 < areas.mean() < 0.78                                   # U(0.5, 1) minus the rejected (too wide / tall) boxes
+        assert all(0.6 <= d["brightness"] <= 1.4 and 0.8 <= d["saturation"] <= 1.2 and -0.1 <= d["hue"] <= 0.1 for d in draws)
+        assert all(0.1 <= d["sigma"] <= 2.0 and sorted(d["order"]) == [0, 1, 2, 3] for d in draws)
+        first = np.bincount([d["order"][0] for d in draws], minlength=4) / len(draws)
+        assert first.min() > 0.2 and first.max() < 0.3                      # every op leads about a quarter of the time
+        assert all(0 <= d["top"] <= 96 - d["h"] and 0 <= d["left"] <= 96 - d["w"] for d in draws)
 
 
 def test_rejects_unsupported(ops):
