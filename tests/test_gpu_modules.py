@@ -241,3 +241,26 @@ def test_supervised_and_dino_trainers(tmp_path):
     trd.fit(1)
     m = trd.train_epoch(2)
     assert m["Loss"] == m["Loss"] and 0.04 <= m["TeacherTemp"] <= 0.07 and 0.996 <= m["Momentum"] <= 1.0
+
+
+def test_dino_trainer_gpu_multicrop(tmp_path):
+    """Loader yields raw uint8 [B,H,W,3] batches; the trainer builds the views on the GPU from
+    the config's transforms.globals / transforms.locals recipes."""
+    from utils.model_builder import build_model
+    from utils.trainers import DINOTrainer
+    torch.manual_seed(8)
+    cfgd = _train_cfg(tmp_path, "dino")
+    cfgd["training"].update(num_all_views=4, num_global_views=2)
+    recipe = lambda size, scale: [                                              # noqa: E731  (configs/dino/{globals,locals}.yaml)
+        {"name": "RandomResizedCrop", "params": {"size": size, "scale": scale}}, {"name": "RandomHorizontalFlip", "params": {}},
+        {"name": "ColorJitter", "params": {"brightness": 0.4, "contrast": 0.4, "saturation": 0.2, "hue": 0.1}},
+        {"name": "GaussianBlur", "params": {"kernel_size": 7, "sigma": [0.1, 2.0]}}, {"name": "ToTensor"}]
+    cfgd["transforms"] = {"globals": recipe(32, [0.5, 1.0]) + [], "locals": recipe(16, [0.08, 0.4])}
+    raw = [torch.randint(0, 256, (4, 40, 40, 3), dtype=torch.uint8) for _ in range(3)]
+    trd = DINOTrainer(build_model(cfgd).to(DEV), str(tmp_path / "dino_mc"), cfgd, raw, raw[:1], DEV)
+    views = trd._views(raw[0])
+    assert [tuple(v.shape) for v in views] == [(4, 3, 32, 32)] * 2 + [(4, 3, 16, 16)] * 2 and views[0].is_cuda
+    m = trd.train_epoch(1)
+    assert m["Loss"] == m["Loss"]
+    v = trd.validate()["Loss"]
+    assert v == v                                                               # finite (fresh random views every call)

@@ -1,7 +1,12 @@
 """DINO trainer (reference: utils/trainers/dino_trainer.py:14-173): per-EPOCH cosine
 schedules for the teacher temperature and the EMA momentum, multi-crop step, teacher
 momentum update after the optimizer step.  Views arrive as a list of V tensors (G global
-first).  AdamW => the fused engine step; otherwise the reference-style autograd path."""
+first).  AdamW => the fused engine step; otherwise the reference-style autograd path.
+
+New: when the loader yields ONE uint8 tensor [B, H, W, 3] of decoded images
+instead of the view list, the views are produced on the GPU by `data.GPUMultiCrop` from the
+`transforms.globals` / `transforms.locals` recipes of the config (the lists the reference
+feeds to torchvision on the CPU, data/datasets.py:80-123)."""
 import logging
 
 import torch
@@ -24,6 +29,17 @@ class DINOTrainer(BaseTrainer):
                                                    t("teacher_temp_warmup_epochs", 30))
         self.mom_sched = DINOMomentumScheduler(t("teacher_momentum_start", 0.996), t("teacher_momentum_final", 1.0), self.num_epochs)
 
+    def _views(self, inputs):
+        if isinstance(inputs, torch.Tensor) and inputs.dtype == torch.uint8 and inputs.dim() == 4:
+            if getattr(self, "_multicrop", None) is None:
+                from data import GPUMultiCrop, ViewSpec
+                tf = cfg_get(self.config, "transforms")
+                t = lambda k, d=None: cfg_get(self.config, "training", k, default=d)  # noqa: E731
+                self._multicrop = GPUMultiCrop(ViewSpec.from_config(tf["globals"]), ViewSpec.from_config(tf["locals"]),
+                                               t("num_all_views", 10), self.num_global_views)
+            return self._multicrop(inputs.to(self.device, non_blocking=True))
+        return [v.to(self.device, non_blocking=True) for v in inputs]
+
     def create_criterion(self):
         t = lambda k, d=None: cfg_get(self.config, "training", k, default=d)  # noqa: E731
         return DINOLoss(teacher_temp=t("teacher_temp_start", 0.04), student_temp=t("student_temp", 0.1))
@@ -42,7 +58,7 @@ class DINOTrainer(BaseTrainer):
         fused = self._is_fused()
         total, running = 0, None
         for idx, inputs in enumerate(self.train_loader):
-            views = [v.to(self.device, non_blocking=True) for v in inputs]
+            views = self._views(inputs)
             if fused:
                 loss = self.model.train_step(views, self.num_global_views, self.criterion, self.optimizer, self.reducer, momentum)
             else:
@@ -63,7 +79,7 @@ class DINOTrainer(BaseTrainer):
         total, running = 0, None
         with torch.no_grad():
             for idx, inputs in enumerate(self.val_loader):
-                views = [v.to(self.device, non_blocking=True) for v in inputs]
+                views = self._views(inputs)
                 loss = self._loss(views)
                 running = loss if running is None else running + loss
                 total += 1
