@@ -88,6 +88,12 @@ def lib():
         raise VitsslError(
             f"{LIB_PATH} not found: the HIP library is not built. Run `python __graft_entry__.py` "
             "(or __graft_entry__.build()). There is no CPU fallback for the vit_core hot path.")
+    # PyTorch-ROCm bundles its own libamdhip64; the process must end up with ONE HIP runtime
+    # (device pointers and streams cross this boundary).  Loading torch first makes the
+    # dynamic loader satisfy this library's libamdhip64.so.7 dependency with torch's copy;
+    # the other order pulls in /opt/rocm's runtime as a second instance and every launch fails
+    # with "no ROCm-capable device is detected" (seen with build() followed by smoke()).
+    import torch  # noqa: F401
     l = C.CDLL(LIB_PATH)
     l.vitssl_last_error.restype = C.c_char_p
     l.vitssl_last_error.argtypes = []
