@@ -14,6 +14,7 @@ ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--dropout", type=float, default=0.1)
+ap.add_argument("--raw", action="store_true", help="start every step from a uint8 [B,96,96,3] batch: views made by GPUMultiCrop")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(42)
@@ -21,13 +22,21 @@ m = DINOViT(12, (3, 224, 224), 768, 16, 12, 3072, a.dropout, 65536, 0.9).to(dev)
 opt = FusedAdamW(m.trainable_store(), lr=1e-4, weight_decay=1e-3)
 crit = DINOLoss(0.04, 0.1)
 B = a.batch
+from vit_core._runtime import limit_host_threads
+limit_host_threads()
 views = [torch.rand(B, 3, 224, 224, device=dev) for _ in range(2)] + [torch.rand(B, 3, 96, 96, device=dev) for _ in range(8)]
+mc = raw = None
+if a.raw:
+    from data import GPUMultiCrop, ViewSpec
+    mc = GPUMultiCrop(ViewSpec(size=224, scale=(0.5, 1.0), gray_p=0.2), ViewSpec(size=96, scale=(0.08, 0.4)), 10, 2)
+    raw = torch.randint(0, 256, (B, 96, 96, 3), dtype=torch.uint8, device=dev)
+step_views = (lambda: mc(raw)) if a.raw else (lambda: views)
 for _ in range(a.warmup):
-    loss = m.train_step(views, 2, crit, opt, None, 0.996)
+    loss = m.train_step(step_views(), 2, crit, opt, None, 0.996)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(a.steps):
-    loss = m.train_step(views, 2, crit, opt, None, 0.996)
+    loss = m.train_step(step_views(), 2, crit, opt, None, 0.996)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
-print(json.dumps({"workload": f"ViT-B/16 DINO 2x224+8x96 K=65536 batch {B}", "ms_per_step": round(dt * 1e3, 2),
+print(json.dumps({"workload": f"ViT-B/16 DINO 2x224+8x96 K=65536 batch {B}" + (" from raw uint8 images (GPU multi-crop)" if a.raw else ""), "ms_per_step": round(dt * 1e3, 2),
                   "image_sets_per_s": round(B / dt, 1), "alg_tflops": round(437.8e9 * B / dt / 1e12, 1),
                   "mfma_util": round(437.8e9 * B / dt / 2.5e15, 4), "loss": round(float(loss), 5)}))
