@@ -177,9 +177,15 @@ __global__ __launch_bounds__(LN_THREADS, (V <= 2 || (V == 3 && !HAS_CS)) ? 4 : (
   }
 }
 
-inline int ln_grid(long long rows) {
+// Blocks of 4 rows, grid-stride.  Backward: every block ends with one atomic per column per
+// accumulated vector, so more blocks cost more (2048: 134 us, 4096: 148, 8192: 225 per launch);
+// parking the partials in a workspace and reducing them in a second launch was measured too
+// (140 us + no change in the step) and dropped.  Forward has no such tail: 4096 blocks give
+// 43.5-43.6 ms per ViT-B step against 43.8 with 2048 (uncapped: 43.7).
+inline int ln_grid(long long rows, bool fwd = false) {
   long long g = (rows + 3) / 4;
-  if (g > 2048) g = 2048;
+  const long long cap = fwd ? 4096 : 2048;
+  if (g > cap) g = cap;
   if (g < 1) g = 1;
   return (int)g;
 }
@@ -216,7 +222,7 @@ extern "C" int vitssl_layernorm_fwd(const float* x, const float* gamma, const fl
                                     float* rstd, int64_t rows, int cols, float eps, void* stream) {
   VS_CHECK_ARG(x && gamma && beta && y_bf16 && mean && rstd, "layernorm_fwd: null pointer");
   VS_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 2048, "layernorm_fwd: cols=%d must be a multiple of 4 and <= 2048", cols);
-  const int grid = ln_grid(rows);
+  const int grid = ln_grid(rows, true);
   hipStream_t s = (hipStream_t)stream;
 #define VS_LNF(V)                                                                                                   \
   hipLaunchKernelGGL(ln_fwd_kernel<V>, dim3(grid), dim3(LN_THREADS), 0, s, x, gamma, beta, (bf16_t*)y_bf16, mean, rstd, \
