@@ -236,3 +236,32 @@ def test_dino_fused_step_runs_and_matches_autograd_loss():
     assert max_abs(model.teacher_head.mlp[0].bias, want) < 1e-6
     loss2 = model.train_step(views, G, crit, opt, None, teacher_momentum=0.9)
     assert torch.isfinite(loss2)
+
+
+@pytest.mark.parametrize("B,img,patch,D,H,F", [(1, 16, 8, 64, 1, 64), (1, 32, 8, 128, 2, 192), (5, 24, 8, 64, 1, 128)])
+def test_edge_batches_against_oracle(B, img, patch, D, H, F):
+    """Smallest shapes the path accepts: a single image, 4 / 9 / 16 tokens (all GEMMs ragged
+    in M, attention with one partial key tile), odd batch: forward, loss and every gradient
+    against the CPU oracle on the same mask."""
+    from vit_core.ssl.simmim import SimMIMViT
+    from vit_core.ssl.simmim.masking import draw_mask
+    torch.manual_seed(B * 100 + img)
+    model = SimMIMViT(num_blocks=2, input_shape=(3, img, img), embed_dim=D, patch_size=patch, num_heads=H, mlp_dim=F,
+                      dropout=0.0, mask_ratio=0.6)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV).train()
+    x = torch.rand(B, 3, img, img)
+    N = (img // patch) ** 2
+    torch.manual_seed(77)
+    mask = draw_mask(B, N, 0.6)
+    torch.manual_seed(77)                                                    # the model draws the same mask
+    pred, tgt, bm = model(x.to(DEV), return_bool_mask=True)
+    assert torch.equal(bm[..., 0].cpu(), mask)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    pe, te = O.simmim_forward(leaves, x, mask, patch, H, emu="bf16")
+    assert pred.shape == pe.shape and torch.equal(tgt.cpu(), te)
+    assert rel_l2(pred, pe) < 1e-2
+    torch.nn.L1Loss()(pred, tgt).backward()
+    O.l1_loss_mean(pe, te).backward()
+    for k, p in model.named_parameters():
+        assert rel_l2(p.grad, leaves[k].grad) < 5e-2, (k, rel_l2(p.grad, leaves[k].grad))
