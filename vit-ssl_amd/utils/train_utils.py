@@ -1,5 +1,13 @@
-"""Reflective factories (reference: utils/train_utils.py:12-51).  AdamW over a model that
-exposes a flat store maps to the fused flat-buffer kernel; anything else is stock torch."""
+"""Factories that turn the `training:` section of a config into objects.
+
+Same entry points and config keys as the reference (utils/train_utils.py:12-51:
+`setup_device`, `make_criterion`, `make_optimizer`, `make_schedulers`; keys `criterion`,
+`optimizer`, `lr_scheduler.{main,warmup}`, `warmup_*`), different machinery: every section is
+read through `_spec` into a (name, kwargs) pair, and an AdamW request over a model that exposes
+its flat parameter store is answered with the fused flat-buffer optimizer kernel instead of
+torch.optim.AdamW.  Transform construction (`get_transforms`) is the data side: see
+`data.ViewSpec.from_config` for the DINO view recipes.
+"""
 import logging
 
 import torch
@@ -10,41 +18,44 @@ from ._config import cfg_get
 from .schedulers import LinearWarmupScheduler
 
 logger = logging.getLogger(__name__)
+_FUSED_ADAMW_KEYS = {"lr", "betas", "eps", "weight_decay"}
+
+
+def _spec(config, *path):
+    """(name, kwargs) of a `{name: ..., params: {...}}` config node."""
+    node = cfg_get(config, *path)
+    return cfg_get(node, "name"), dict(cfg_get(node, "params", default={}) or {})
 
 
 def setup_device():
+    """The engine has no CPU path, so unlike the reference this refuses to hand out 'cpu'."""
     if not torch.cuda.is_available():
         raise RuntimeError("no GPU visible: this engine runs the vit_core hot path on MI355X only (no CPU fallback)")
     device = torch.device("cuda")
-    logger.info(f"Using device: {device}")
+    logger.info("Using device: %s", device)
     return device
 
 
 def make_criterion(config):
-    crit = cfg_get(config, "training", "criterion")
-    cls = getattr(nn, cfg_get(crit, "name"))
-    return cls(**dict(cfg_get(crit, "params", default={}) or {}))
+    name, kwargs = _spec(config, "training", "criterion")
+    return getattr(nn, name)(**kwargs)
 
 
 def make_optimizer(config, model):
-    opt = cfg_get(config, "training", "optimizer")
-    name = cfg_get(opt, "name")
-    params = dict(cfg_get(opt, "params", default={}) or {})
-    flat = getattr(model, "flat_store", None)
-    if name == "AdamW" and flat is not None and set(params) <= {"lr", "betas", "eps", "weight_decay"}:
+    name, kwargs = _spec(config, "training", "optimizer")
+    if name == "AdamW" and hasattr(model, "flat_store") and set(kwargs) <= _FUSED_ADAMW_KEYS:
         from vitssl_hip.optim import FusedAdamW
-        store = model.trainable_store() if hasattr(model, "trainable_store") else flat()
-        return FusedAdamW(store, **params)
-    trainable = [p for p in model.parameters() if p.requires_grad]
-    return getattr(optim, name)(trainable, **params)
+        store = model.trainable_store() if hasattr(model, "trainable_store") else model.flat_store()
+        return FusedAdamW(store, **kwargs)
+    return getattr(optim, name)((p for p in model.parameters() if p.requires_grad), **kwargs)
 
 
 def make_schedulers(config, optimizer, num_epochs, warmup_steps):
-    sched = cfg_get(config, "training", "lr_scheduler")
-    main, warm = cfg_get(sched, "main"), cfg_get(sched, "warmup")
-    main_cls = getattr(lr_scheduler, cfg_get(main, "name"))
-    main_kwargs = dict(cfg_get(main, "params", default={}) or {}, T_max=num_epochs - cfg_get(config, "training", "warmup_epochs"))
-    warm_kwargs = dict(cfg_get(warm, "params", default={}) or {}, warmup_steps=warmup_steps,
-                       start_lr=cfg_get(config, "training", "warmup_initial_learning_rate"),
-                       target_lr=cfg_get(config, "training", "warmup_final_learning_rate"))
-    return {"main": main_cls(optimizer, **main_kwargs), "warmup": LinearWarmupScheduler(optimizer, **warm_kwargs)}
+    """{"main": per-epoch torch scheduler, "warmup": per-step linear ramp}"""
+    train = lambda key: cfg_get(config, "training", key)  # noqa: E731
+    main_name, main_kwargs = _spec(config, "training", "lr_scheduler", "main")
+    _, ramp_kwargs = _spec(config, "training", "lr_scheduler", "warmup")
+    main_kwargs["T_max"] = num_epochs - train("warmup_epochs")           # cosine over the post-warm-up epochs
+    ramp = LinearWarmupScheduler(optimizer, warmup_steps=warmup_steps, start_lr=train("warmup_initial_learning_rate"),
+                                 target_lr=train("warmup_final_learning_rate"), **ramp_kwargs)
+    return {"main": getattr(lr_scheduler, main_name)(optimizer, **main_kwargs), "warmup": ramp}

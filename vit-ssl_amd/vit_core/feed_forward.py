@@ -1,6 +1,12 @@
-"""FeedForwardBlock (reference: vit_core/feed_forward.py:7-28): Linear -> GELU(erf) ->
-Dropout -> Linear.  Parameters are ordinary nn.Linear weights (same init / state_dict
-keys); the forward is two MFMA GEMMs with the bias+GELU+dropout epilogue fused."""
+"""Transformer MLP block on the HIP engine.
+
+Module surface of the reference (vit_core/feed_forward.py:7-28): `FeedForwardBlock(d_model,
+d_ff, dropout)` with `linear_in`, `linear_out` (ordinary nn.Linear parameters: same init,
+same checkpoint keys) and `dropout`.  Semantics: linear_out(dropout(gelu_erf(linear_in(x)))).
+Execution: two bf16 MFMA GEMMs; bias, exact-erf GELU and the counter-based dropout mask are
+applied in the first GEMM's epilogue (which also stores keep*gelu'(u) for the backward), the
+second GEMM adds its bias in fp32 (`ffn_apply`, a torch.autograd.Function).
+"""
 import torch
 from torch import nn
 
@@ -15,7 +21,15 @@ class FeedForwardBlock(nn.Module):
         self.linear_out = nn.Linear(d_ff, d_model)
         self.dropout = nn.Dropout(dropout)
 
+    def _drop_p(self) -> float:
+        """dropout probability in effect: the module's p while training, 0 in eval"""
+        return float(self.dropout.p) if self.training else 0.0
+
+    def extra_repr(self) -> str:
+        return f"fused GEMM+GELU+dropout epilogue, hidden {self.linear_in.out_features}"
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x: [..., d_model] fp32 on the GPU -> same shape."""
         R.require_gpu(x, "FeedForwardBlock")
-        p = self.dropout.p if self.training else 0.0
-        return ffn_apply(x, self.linear_in.weight, self.linear_in.bias, self.linear_out.weight, self.linear_out.bias, p)
+        fc1, fc2 = self.linear_in, self.linear_out
+        return ffn_apply(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias, self._drop_p())
