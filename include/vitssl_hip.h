@@ -221,6 +221,13 @@ int vitssl_colsum_f32(const float* x, float* out, int64_t rows, int cols, void* 
 /* center = m center + (1-m) colsum * inv_rows   (all-reduce colsum first under data parallelism) */
 int vitssl_center_ema(float* center, const float* colsum, int K, float momentum, float inv_rows, void* stream);
 
+/* Positional-table resize of DynamicPatchEmbedding.interpolate_pos_encoding
+ * (vit_core/patch_embedding.py:26-48): F.interpolate(mode="bicubic", align_corners=False) of the
+ * patch rows, channel-last.  src f32 [gh0*gw0, D] -> dst f32 [gh*gw, D]; the backward
+ * ACCUMULATES into dsrc f32 [gh0*gw0, D]. */
+int vitssl_bicubic_resize_fwd(const float* src, float* dst, int gh0, int gw0, int gh, int gw, int D, void* stream);
+int vitssl_bicubic_resize_bwd(const float* ddst, float* dsrc, int gh0, int gw0, int gh, int gw, int D, void* stream);
+
 /* ---- DINO multi-crop input pipeline -------------------------------
  * Replaces, per view, the torchvision transform list that data/datasets.py:80-123
  * (STL10DINODataset._get_dino_views) applies on the CPU with PIL images:

@@ -486,3 +486,25 @@ def test_ema(ops):
     td = gpu(tt.clone())
     ops.ema(td, gpu(ss), 0.996)
     assert max_abs(td, O.ema_update(tt, ss, 0.996)) < 1e-6
+
+
+@pytest.mark.parametrize("g0,g1", [((14, 14), (6, 6)), ((4, 4), (6, 6)), ((4, 4), (2, 2)), ((6, 6), (3, 5)), ((5, 7), (14, 14))])
+def test_bicubic_resize_matches_aten_and_oracle(ops, g0, g1):
+    """positional-table resize (DynamicPatchEmbedding.interpolate_pos_encoding): forward against
+    F.interpolate on the GPU and the CPU oracle, backward against autograd of the same op"""
+    torch.manual_seed(g0[0] * 10 + g1[0])
+    D = 192
+    src = torch.randn(g0[0] * g0[1], D)
+    dst = torch.empty(g1[0] * g1[1], D, device=DEV)
+    ops.bicubic_resize_fwd(gpu(src), dst, g0[0], g0[1], g1[0], g1[1])
+    leaf = src.clone().to(DEV).requires_grad_(True)
+    ref = torch.nn.functional.interpolate(leaf.reshape(1, g0[0], g0[1], D).permute(0, 3, 1, 2), size=g1, mode="bicubic")
+    ref_rows = ref.permute(0, 2, 3, 1).reshape(-1, D)
+    assert max_abs(dst, ref_rows.detach()) < 2e-5
+    ora = O.bicubic_resize(src.reshape(1, g0[0], g0[1], D).permute(0, 3, 1, 2), g1[0], g1[1]).permute(0, 2, 3, 1).reshape(-1, D)
+    assert max_abs(dst, ora) < 2e-5
+    gout = torch.randn(g1[0] * g1[1], D)
+    ref_rows.backward(gout.to(DEV))
+    dsrc = torch.full((g0[0] * g0[1], D), 0.5, device=DEV)                 # accumulates
+    ops.bicubic_resize_bwd(gpu(gout), dsrc, g0[0], g0[1], g1[0], g1[1])
+    assert max_abs(dsrc - 0.5, leaf.grad) < 5e-5

@@ -195,6 +195,64 @@ __global__ void center_ema_kernel(float* __restrict__ center, const float* __res
   if (k < K) center[k] = mom * center[k] + (1.f - mom) * colsum[k] * inv_rows;
 }
 
+// ------------------------------------------------------------------ positional-table resize
+// F.interpolate(mode="bicubic", align_corners=False) of the patch part of the positional
+// embedding (vit_core/patch_embedding.py:26-48), channel-last: src [gh0*gw0, D] -> dst [gh*gw, D].
+// ATen's upsample_bicubic2d: source coordinate (dst + 0.5) * in/out - 0.5 (not clamped), Keys
+// kernel A = -0.75, taps clamped to the border, rows interpolated along x first, then along y.
+__device__ __forceinline__ void cubic_coeffs(float t, float c[4]) {
+  const float A = -0.75f;
+  const float x0 = t + 1.0f, x1 = t, x2 = 1.0f - t, x3 = 2.0f - t;
+  c[0] = ((A * x0 - 5.0f * A) * x0 + 8.0f * A) * x0 - 4.0f * A;
+  c[1] = ((A + 2.0f) * x1 - (A + 3.0f)) * x1 * x1 + 1.0f;
+  c[2] = ((A + 2.0f) * x2 - (A + 3.0f)) * x2 * x2 + 1.0f;
+  c[3] = ((A * x3 - 5.0f * A) * x3 + 8.0f * A) * x3 - 4.0f * A;
+}
+
+__device__ __forceinline__ void cubic_site(int dst, int in_n, int out_n, int idx[4], float c[4]) {
+  const float scale = (float)in_n / (float)out_n;
+  const float real = scale * ((float)dst + 0.5f) - 0.5f;
+  const float fl = floorf(real);
+  cubic_coeffs(real - fl, c);
+  const int i0 = (int)fl;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) idx[k] = min(max(i0 - 1 + k, 0), in_n - 1);
+}
+
+// grid = gh*gw output tokens, threads over D
+__global__ void bicubic_fwd_kernel(const float* __restrict__ src, float* __restrict__ dst, int gh0, int gw0, int gh, int gw, int D) {
+  const int y = blockIdx.x / gw, x = blockIdx.x - y * gw;
+  int iy[4], ix[4];
+  float cy[4], cx[4];
+  cubic_site(y, gh0, gh, iy, cy);
+  cubic_site(x, gw0, gw, ix, cx);
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    float rows[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float* r = src + (long long)iy[i] * gw0 * D + d;
+      rows[i] = r[(long long)ix[0] * D] * cx[0] + r[(long long)ix[1] * D] * cx[1] + r[(long long)ix[2] * D] * cx[2] + r[(long long)ix[3] * D] * cx[3];
+    }
+    dst[(long long)blockIdx.x * D + d] = rows[0] * cy[0] + rows[1] * cy[1] + rows[2] * cy[2] + rows[3] * cy[3];
+  }
+}
+
+// dsrc[tap] += wy * wx * ddst (atomics: 16 taps per output token, a few hundred tokens)
+__global__ void bicubic_bwd_kernel(const float* __restrict__ ddst, float* __restrict__ dsrc, int gh0, int gw0, int gh, int gw, int D) {
+  const int y = blockIdx.x / gw, x = blockIdx.x - y * gw;
+  int iy[4], ix[4];
+  float cy[4], cx[4];
+  cubic_site(y, gh0, gh, iy, cy);
+  cubic_site(x, gw0, gw, ix, cx);
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    const float g = ddst[(long long)blockIdx.x * D + d];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) atomicAdd(dsrc + ((long long)iy[i] * gw0 + ix[j]) * D + d, g * cy[i] * cx[j]);
+  }
+}
+
 }  // namespace
 
 extern "C" int vitssl_rownorm_fwd(const float* z, void* zn_bf16, float* inv_norm, int64_t rows, int cols, void* stream) {
@@ -255,5 +313,19 @@ extern "C" int vitssl_center_ema(float* center, const float* colsum, int K, floa
   VS_CHECK_ARG(center && colsum && K > 0, "center_ema: bad args");
   hipLaunchKernelGGL(center_ema_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, center, colsum, K, momentum, inv_rows);
   VS_CHECK_LAUNCH("center_ema");
+  return VITSSL_OK;
+}
+
+extern "C" int vitssl_bicubic_resize_fwd(const float* src, float* dst, int gh0, int gw0, int gh, int gw, int D, void* stream) {
+  VS_CHECK_ARG(src && dst && gh0 > 0 && gw0 > 0 && gh > 0 && gw > 0 && D > 0, "bicubic_resize_fwd: bad args");
+  hipLaunchKernelGGL(bicubic_fwd_kernel, dim3(gh * gw), dim3(256), 0, (hipStream_t)stream, src, dst, gh0, gw0, gh, gw, D);
+  VS_CHECK_LAUNCH("bicubic_resize_fwd");
+  return VITSSL_OK;
+}
+
+extern "C" int vitssl_bicubic_resize_bwd(const float* ddst, float* dsrc, int gh0, int gw0, int gh, int gw, int D, void* stream) {
+  VS_CHECK_ARG(ddst && dsrc && gh0 > 0 && gw0 > 0 && gh > 0 && gw > 0 && D > 0, "bicubic_resize_bwd: bad args");
+  hipLaunchKernelGGL(bicubic_bwd_kernel, dim3(gh * gw), dim3(256), 0, (hipStream_t)stream, ddst, dsrc, gh0, gw0, gh, gw, D);
+  VS_CHECK_LAUNCH("bicubic_resize_bwd");
   return VITSSL_OK;
 }

@@ -2,7 +2,6 @@
 Shared by ViT (vit_core/vit.py:33-45) and the DINO backbones
 (vit_core/ssl/dino/model.py:34-45)."""
 import torch
-import torch.nn.functional as Fnn
 
 from . import _runtime as R
 from ._runtime import BF16, F32, L, ops
@@ -32,14 +31,11 @@ class BackboneRuntime:
         pos = st.view(self.names["pos"], (1, self.T0, self.D))
         if gh * gw == self.grid[0] * self.grid[1] and gh == gw:
             return pos[0], None
-        leaf = pos.detach().requires_grad_(need_grad)
-        with torch.enable_grad():
-            cls_pos = leaf[:, 0]
-            pp = leaf[:, 1:].reshape(1, self.grid[0], self.grid[1], self.D).permute(0, 3, 1, 2)
-            pp = Fnn.interpolate(pp, size=(gh, gw), mode="bicubic")
-            pp = pp.permute(0, 2, 3, 1).reshape(1, -1, self.D)
-            full = torch.cat((cls_pos.unsqueeze(0), pp), dim=1)[0].contiguous()
-        return full.detach(), (leaf, full)
+        # CLS row copied, patch rows resampled on the grid (bicubic, as F.interpolate does it)
+        full = torch.empty(gh * gw + 1, self.D, dtype=F32, device=pos.device)
+        full[0] = pos[0, 0]
+        ops.bicubic_resize_fwd(pos[0, 1:], full[1:], self.grid[0], self.grid[1], gh, gw)
+        return full, (gh, gw)
 
     def forward(self, x, training: bool, seed: int, save: bool, slot: str, return_attn=False, dynamic=False):
         """x: fp32 [B, C, Himg, Wimg] -> (cls features fp32 [B, D], attn probs or None)."""
@@ -84,10 +80,11 @@ class BackboneRuntime:
         else:
             dpos = torch.zeros(T, self.D, dtype=F32, device=dev)
         ops.embed_bwd(g, None, dproj, dpos, None, gv(self.names["bias"]), gv(self.names["cls"]), B, tokens, 1, self.D)
-        if rec["pos_graph"] is not None:
-            leaf, full = rec["pos_graph"]
-            (dleaf,) = torch.autograd.grad(full, leaf, dpos)
-            gv(self.names["pos"]).add_(dleaf.reshape(-1))
+        if rec["pos_graph"] is not None:                       # resized table: route d(pos) back through the resize
+            gh, gw = rec["pos_graph"]
+            gpos = gv(self.names["pos"], (self.T0, self.D))
+            gpos[0].add_(dpos[0])                               # CLS row: identity
+            ops.bicubic_resize_bwd(dpos[1:], gpos[1:], self.grid[0], self.grid[1], gh, gw)
         ops.gemm_tn(dproj, rec["patches"], gv(self.names["weight"], (self.D, self.Pd)))
         # the CLS position also receives the CLS-row gradient through `cls + pos[0]`:
         # embed_bwd already added row 0 of every image to dpos[0] and to dcls.

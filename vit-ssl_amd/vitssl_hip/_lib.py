@@ -56,6 +56,8 @@ PROTOTYPES = {
     "vitssl_cast_bf16": [_vp, _vp, _i64, _vp],
     "vitssl_cast_transpose_bf16": [_vp, _vp, _vp, _i, _i, _vp],
     "vitssl_cast_transpose_batch": [_vp, _vp, _i, _i, _vp],
+    "vitssl_bicubic_resize_fwd": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "vitssl_bicubic_resize_bwd": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "vitssl_aug_resized_crop_u8": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "vitssl_aug_color_u8": [_vp, _vp, _vp, _i, _i, _vp],
     "vitssl_aug_blur_to_tensor": [_vp, _vp, _vp, _i, _i, _i, _vp],

@@ -340,6 +340,18 @@ def center_ema(center, colsum, momentum, inv_rows):
     call("vitssl_center_ema", _chk(center, F32, "center"), _chk(colsum, F32, "colsum"), K, float(momentum), float(inv_rows), _stream())
 
 
+def bicubic_resize_fwd(src, dst, gh0, gw0, gh, gw):
+    D = src.shape[1]
+    call("vitssl_bicubic_resize_fwd", _chk(src, F32, "src", (gh0 * gw0, D)), _chk(dst, F32, "dst", (gh * gw, D)),
+         gh0, gw0, gh, gw, D, _stream())
+
+
+def bicubic_resize_bwd(ddst, dsrc, gh0, gw0, gh, gw):
+    D = ddst.shape[1]
+    call("vitssl_bicubic_resize_bwd", _chk(ddst, F32, "ddst", (gh * gw, D)), _chk(dsrc, F32, "dsrc", (gh0 * gw0, D)),
+         gh0, gw0, gh, gw, D, _stream())
+
+
 # ---- DINO multi-crop input pipeline (data/datasets.py:80-123) -------------------------------
 AUG_IP, AUG_FP = 11, 10
 
