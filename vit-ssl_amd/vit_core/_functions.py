@@ -461,3 +461,28 @@ class _PatchEmbedFn(Function):
 
 def patch_embed_apply(img, w, b, cls, pos, P):
     return _PatchEmbedFn.apply(img, w, b, cls, pos, P)
+
+
+class _BicubicRowsFn(Function):
+    """Bicubic resize of a channel-last token grid [gh0*gw0, D] -> [gh*gw, D] (the patch rows
+    of a positional table), ATen-compatible, forward and backward on the HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, rows, gh0, gw0, gh, gw):
+        rows = R.as_f32(rows)
+        out = _empty((gh * gw, rows.shape[1]), F32, rows)
+        ops.bicubic_resize_fwd(rows, out, gh0, gw0, gh, gw)
+        ctx.dims = (gh0, gw0, gh, gw)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        gh0, gw0, gh, gw = ctx.dims
+        gout = R.as_f32(gout)
+        gin = torch.zeros(gh0 * gw0, gout.shape[1], dtype=F32, device=gout.device)
+        ops.bicubic_resize_bwd(gout, gin, gh0, gw0, gh, gw)
+        return gin, None, None, None, None
+
+
+def bicubic_rows_apply(rows, src_grid, dst_grid):
+    return _BicubicRowsFn.apply(rows, src_grid[0], src_grid[1], dst_grid[0], dst_grid[1])

@@ -10,10 +10,9 @@ prepend plus the positional add happen in that GEMM's epilogue (`patch_embed_app
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import _runtime as R
-from ._functions import patch_embed_apply
+from ._functions import bicubic_rows_apply, patch_embed_apply
 
 
 def _grid_of(input_shape, patch_size, strict):
@@ -54,10 +53,9 @@ class DynamicPatchEmbedding(_TokenTable):
         table = self.positional_embedding
         if rows == cols and rows * cols == self.num_patches:
             return table
-        width = table.shape[-1]
-        grid = table[:, 1:].reshape(1, *self.grid_size, width).movedim(-1, 1)        # [1, D, gh, gw]
-        grid = F.interpolate(grid, size=(rows, cols), mode="bicubic")
-        return torch.cat((table[:, :1], grid.movedim(1, -1).reshape(1, rows * cols, width)), dim=1)
+        R.require_gpu(table, "DynamicPatchEmbedding")
+        patch_rows = bicubic_rows_apply(table[0, 1:], self.grid_size, (rows, cols))  # ATen-compatible bicubic, HIP
+        return torch.cat((table[0, :1], patch_rows), dim=0).unsqueeze(0)
 
     def interpolate_pos_encoding(self, x, w, h):
         """Reference-compatible spelling (patch tokens, grid rows, grid cols); only the token
