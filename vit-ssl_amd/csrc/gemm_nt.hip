@@ -306,139 +306,156 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
     if constexpr (EPI == VITSSL_EPI_RESID) rsAux = window(p.aux, 4);
     if constexpr (EPI == VITSSL_EPI_DGELU) rsAux = window(p.aux, 2);
 
+    // Column bookkeeping of this wave's 64 columns: pair jp covers tiles (2jp, 2jp+1), half h
+    // of a pair is one 16-column tile; a lane owns 4 consecutive columns of each.
+    int nn[2][2];
+    bool okn[2][2];
+    f32x4 bias4[2][2];
   #pragma unroll
-    for (int jp = 0; jp < 2; ++jp) {
-      const int nA = n0 + wn * 64 + (2 * jp) * 16 + 4 * g4;
-      const int nB = nA + 16;
-      const bool okA = nA < p.N, okB = nB < p.N;
-      f32x4 biasA = {0.f, 0.f, 0.f, 0.f}, biasB = biasA;
-      if (p.bias && (EPI != EPI_F32_SPLITK || blockIdx.y == 0)) {
-        if (okA) biasA = *(const f32x4*)(p.bias + nA);
-        if (okB) biasB = *(const f32x4*)(p.bias + nB);
+    for (int jp = 0; jp < 2; ++jp)
+  #pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        nn[jp][h] = n0 + wn * 64 + (2 * jp + h) * 16 + 4 * g4;
+        okn[jp][h] = nn[jp][h] < p.N;
+        bias4[jp][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias && (EPI != EPI_F32_SPLITK || blockIdx.y == 0) && okn[jp][h]) bias4[jp][h] = *(const f32x4*)(p.bias + nn[jp][h]);
       }
-      const int nn[2] = {nA, nB};
-      const bool okn[2] = {okA, okB};
 
-      // ---- operand prefetch for this half: every load in flight before the first use
-      f32x4 res[4][2];     // RESID: residual stream, rows 16*i4 .. of the current group of four
-      u32x2 gpre[8][2];    // DGELU: g' in accumulator layout
-      auto load_res = [&](int ih) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int h = 0; h < 2; ++h)
-            res[i][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_elem(ih * 4 + i, nn[h], 4u), 0, 0));
-      };
+    // Rows are walked in groups; inside a group the loop order is row -> pair, so the two
+    // 64-byte halves of every 128-byte output line are stored by consecutive instructions
+    // (pair-major order left them half an epilogue apart and the second bf16 image of the GELU
+    // epilogue was written at ~3 TB/s).  The residual / g' operands of a whole group are
+    // loaded before its first use.
+    constexpr int RG = (EPI == VITSSL_EPI_RESID) ? 2 : 4;
+  #pragma unroll
+    for (int ig = 0; ig < 8; ig += RG) {
+      f32x4 res[RG][2][2];     // RESID: residual stream
+      u32x2 gpre[RG][2][2];    // DGELU: g' in accumulator layout
+      if constexpr (EPI == VITSSL_EPI_RESID) {
+  #pragma unroll
+        for (int ii = 0; ii < RG; ++ii)
+  #pragma unroll
+          for (int jp = 0; jp < 2; ++jp)
+  #pragma unroll
+            for (int h = 0; h < 2; ++h)
+              res[ii][jp][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_elem(ig + ii, nn[jp][h], 4u), 0, 0));
+      }
       if constexpr (EPI == VITSSL_EPI_DGELU) {
         if (wide) {
-          u32x4 raw[8];
+          u32x4 raw[RG][2];
   #pragma unroll
-          for (int i = 0; i < 8; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_bf16_wide(i, jp), 0, 0);
+          for (int ii = 0; ii < RG; ++ii)
   #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            // inverse of the store shuffle (the swap is an involution)
-            auto a = __builtin_amdgcn_permlane16_swap(raw[i][0], raw[i][2], false, false);
-            auto b = __builtin_amdgcn_permlane16_swap(raw[i][1], raw[i][3], false, false);
-            gpre[i][0] = u32x2{a[0], b[0]};
-            gpre[i][1] = u32x2{a[1], b[1]};
-          }
+            for (int jp = 0; jp < 2; ++jp) raw[ii][jp] = __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_bf16_wide(ig + ii, jp), 0, 0);
+  #pragma unroll
+          for (int ii = 0; ii < RG; ++ii)
+  #pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+              // inverse of the store shuffle (the swap is an involution)
+              auto sa = __builtin_amdgcn_permlane16_swap(raw[ii][jp][0], raw[ii][jp][2], false, false);
+              auto sb = __builtin_amdgcn_permlane16_swap(raw[ii][jp][1], raw[ii][jp][3], false, false);
+              gpre[ii][jp][0] = u32x2{sa[0], sb[0]};
+              gpre[ii][jp][1] = u32x2{sa[1], sb[1]};
+            }
         } else {
   #pragma unroll
-          for (int i = 0; i < 8; ++i)
+          for (int ii = 0; ii < RG; ++ii)
   #pragma unroll
-            for (int h = 0; h < 2; ++h) gpre[i][h] = __builtin_amdgcn_raw_buffer_load_b64(rsAux, off_elem(i, nn[h], 2u), 0, 0);
+            for (int jp = 0; jp < 2; ++jp)
+  #pragma unroll
+              for (int h = 0; h < 2; ++h) gpre[ii][jp][h] = __builtin_amdgcn_raw_buffer_load_b64(rsAux, off_elem(ig + ii, nn[jp][h], 2u), 0, 0);
         }
       }
 
   #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        if constexpr (EPI == VITSSL_EPI_RESID) {
-          if (i == 0) load_res(0);
-          if (i == 4) load_res(1);
-        }
+      for (int ii = 0; ii < RG; ++ii) {
+        const int i = ig + ii;
         const long long m = m0 + wm * 128 + i * 16 + (lane & 15);
         const bool okm = m < p.M;
-        f32x4 v[2] = {acc[2 * jp][i] + biasA, acc[2 * jp + 1][i] + biasB};
+  #pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+          f32x4 v[2] = {acc[2 * jp][i] + bias4[jp][0], acc[2 * jp + 1][i] + bias4[jp][1]};
 
-        if constexpr (EPI == VITSSL_EPI_BF16) {
-          const u32x2 w0 = {pack_bf2(v[0][0], v[0][1]), pack_bf2(v[0][2], v[0][3])};
-          const u32x2 w1 = {pack_bf2(v[1][0], v[1][1]), pack_bf2(v[1][2], v[1][3])};
-          store_bf16_pair(rsOut0, i, jp, w0, w1);
-        } else if constexpr (EPI == VITSSL_EPI_GELU) {
-          // u = bf16(acc + bias) (never stored); out1 = a = keep*scale*gelu(u) feeds the next
-          // GEMM; out0 = g' = keep*scale*gelu'(u) is what the backward dGELU epilogue needs.
-          u32x2 gp[2], a[2];
+          if constexpr (EPI == VITSSL_EPI_BF16) {
+            const u32x2 w0 = {pack_bf2(v[0][0], v[0][1]), pack_bf2(v[0][2], v[0][3])};
+            const u32x2 w1 = {pack_bf2(v[1][0], v[1][1]), pack_bf2(v[1][2], v[1][3])};
+            store_bf16_pair(rsOut0, i, jp, w0, w1);
+          } else if constexpr (EPI == VITSSL_EPI_GELU) {
+            // u = bf16(acc + bias) (never stored); out1 = a = keep*scale*gelu(u) feeds the next
+            // GEMM; out0 = g' = keep*scale*gelu'(u) is what the backward dGELU epilogue needs.
+            u32x2 gp[2], a[2];
   #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            float mult[4] = {1.f, 1.f, 1.f, 1.f};
-            if (p.drop_on) drop_mult4(p.dk, (unsigned long long)(m * p.N + nn[h]) >> 2, mult);
-            float y[4], d[4];
+            for (int h = 0; h < 2; ++h) {
+              float mult[4] = {1.f, 1.f, 1.f, 1.f};
+              if (p.drop_on) drop_mult4(p.dk, (unsigned long long)(m * p.N + nn[jp][h]) >> 2, mult);
+              float y[4], d[4];
   #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              gelu_both(round_bf(v[h][r]), y[r], d[r]);
-              y[r] *= mult[r];
-              d[r] *= mult[r];
+              for (int r = 0; r < 4; ++r) {
+                gelu_both(round_bf(v[h][r]), y[r], d[r]);
+                y[r] *= mult[r];
+                d[r] *= mult[r];
+              }
+              a[h] = u32x2{pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
+              gp[h] = u32x2{pack_bf2(d[0], d[1]), pack_bf2(d[2], d[3])};
             }
-            a[h] = u32x2{pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
-            gp[h] = u32x2{pack_bf2(d[0], d[1]), pack_bf2(d[2], d[3])};
-          }
-          store_bf16_pair(rsOut0, i, jp, gp[0], gp[1]);
-          store_bf16_pair(rsOut1, i, jp, a[0], a[1]);
-        } else if constexpr (EPI == VITSSL_EPI_DGELU) {
-          // du = acc * g'  (g' already carries the dropout mask and its scale)
-          u32x2 w[2];
+            store_bf16_pair(rsOut0, i, jp, gp[0], gp[1]);
+            store_bf16_pair(rsOut1, i, jp, a[0], a[1]);
+          } else if constexpr (EPI == VITSSL_EPI_DGELU) {
+            // du = acc * g'  (g' already carries the dropout mask and its scale)
+            u32x2 w[2];
   #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const u32x2 gpv = gpre[i][h];
-            v[h][0] *= bf_lo(gpv[0]);
-            v[h][1] *= bf_hi(gpv[0]);
-            v[h][2] *= bf_lo(gpv[1]);
-            v[h][3] *= bf_hi(gpv[1]);
-            w[h] = u32x2{pack_bf2(v[h][0], v[h][1]), pack_bf2(v[h][2], v[h][3])};
-          }
-          store_bf16_pair(rsOut0, i, jp, w[0], w[1]);
-        } else if constexpr (EPI == EPI_F32_SPLITK) {
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            if (!(okm && okn[h])) continue;
-            float* o = (float*)p.out0 + m * p.N + nn[h];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) unsafeAtomicAdd(o + r, v[h][r]);
-          }
-        } else if constexpr (EPI == VITSSL_EPI_F32) {
-  #pragma unroll
-          for (int h = 0; h < 2; ++h)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[h]), rsOut0, off_elem(i, nn[h], 4u), 0, 0);
-        } else if constexpr (EPI == VITSSL_EPI_RESID) {
-  #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            if (p.drop_on) {
-              float mult[4];
-              drop_mult4(p.dk, (unsigned long long)(m * p.N + nn[h]) >> 2, mult);
-              v[h][0] *= mult[0]; v[h][1] *= mult[1]; v[h][2] *= mult[2]; v[h][3] *= mult[3];
+            for (int h = 0; h < 2; ++h) {
+              const u32x2 gpv = gpre[ii][jp][h];
+              v[h][0] *= bf_lo(gpv[0]);
+              v[h][1] *= bf_hi(gpv[0]);
+              v[h][2] *= bf_lo(gpv[1]);
+              v[h][3] *= bf_hi(gpv[1]);
+              w[h] = u32x2{pack_bf2(v[h][0], v[h][1]), pack_bf2(v[h][2], v[h][3])};
             }
-            v[h] += res[i & 3][h];
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[h]), rsOut0, off_elem(i, nn[h], 4u), 0, 0);
-          }
-        } else {   // VITSSL_EPI_EMBED (one launch per step: plain addressing)
+            store_bf16_pair(rsOut0, i, jp, w[0], w[1]);
+          } else if constexpr (EPI == EPI_F32_SPLITK) {
   #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            if (!(okm && okn[h])) continue;
-            const long long img = m / p.embed.tokens;
-            const int rin = (int)(m - img * p.embed.tokens);
-            if (p.embed.mask && p.embed.mask[m]) v[h] = *(const f32x4*)(p.embed.mask_token + nn[h]);
-            v[h] += *(const f32x4*)(p.embed.pos + (long long)(p.embed.tok_offset + rin) * p.N + nn[h]);
-            const long long orow = img * p.embed.out_tokens + p.embed.tok_offset + rin;
-            *(f32x4*)((float*)p.out0 + orow * p.N + nn[h]) = v[h];
-          }
-        }
-        if (p.colsum) {
+            for (int h = 0; h < 2; ++h) {
+              if (!(okm && okn[jp][h])) continue;
+              float* o = (float*)p.out0 + m * p.N + nn[jp][h];
   #pragma unroll
-          for (int h = 0; h < 2; ++h)
-            if (okm && okn[h]) {
-  #pragma unroll
-              for (int r = 0; r < 4; ++r) csum[2 * jp + h][r] += v[h][r];
+              for (int r = 0; r < 4; ++r) unsafeAtomicAdd(o + r, v[h][r]);
             }
+          } else if constexpr (EPI == VITSSL_EPI_F32) {
+  #pragma unroll
+            for (int h = 0; h < 2; ++h)
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[h]), rsOut0, off_elem(i, nn[jp][h], 4u), 0, 0);
+          } else if constexpr (EPI == VITSSL_EPI_RESID) {
+  #pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              if (p.drop_on) {
+                float mult[4];
+                drop_mult4(p.dk, (unsigned long long)(m * p.N + nn[jp][h]) >> 2, mult);
+                v[h][0] *= mult[0]; v[h][1] *= mult[1]; v[h][2] *= mult[2]; v[h][3] *= mult[3];
+              }
+              v[h] += res[ii][jp][h];
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[h]), rsOut0, off_elem(i, nn[jp][h], 4u), 0, 0);
+            }
+          } else {   // VITSSL_EPI_EMBED (one launch per step: plain addressing)
+  #pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              if (!(okm && okn[jp][h])) continue;
+              const long long img = m / p.embed.tokens;
+              const int rin = (int)(m - img * p.embed.tokens);
+              if (p.embed.mask && p.embed.mask[m]) v[h] = *(const f32x4*)(p.embed.mask_token + nn[jp][h]);
+              v[h] += *(const f32x4*)(p.embed.pos + (long long)(p.embed.tok_offset + rin) * p.N + nn[jp][h]);
+              const long long orow = img * p.embed.out_tokens + p.embed.tok_offset + rin;
+              *(f32x4*)((float*)p.out0 + orow * p.N + nn[jp][h]) = v[h];
+            }
+          }
+          if (p.colsum) {
+  #pragma unroll
+            for (int h = 0; h < 2; ++h)
+              if (okm && okn[jp][h]) {
+  #pragma unroll
+                for (int r = 0; r < 4; ++r) csum[2 * jp + h][r] += v[h][r];
+              }
+          }
         }
       }
     }
@@ -463,8 +480,8 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
     // The next tile's first stage was issued before every store above; vector-memory
     // operations retire in issue order, so "at most <the stores of the last half> still in
     // flight" implies that DMA has landed, without waiting for the stores themselves.
-    constexpr int TAIL = (EPI == VITSSL_EPI_GELU || EPI == VITSSL_EPI_F32 || EPI == VITSSL_EPI_RESID) ? 16
-                         : ((EPI == VITSSL_EPI_EMBED || EPI == EPI_F32_SPLITK) ? 0 : 8);
+    constexpr int TAIL = (EPI == VITSSL_EPI_GELU || EPI == VITSSL_EPI_F32) ? 16
+                         : ((EPI == VITSSL_EPI_EMBED || EPI == EPI_F32_SPLITK) ? 0 : 8);   // stores of the last row group
     wait_vmcnt<TAIL>();
     m0 = m0n;
     n0 = n0n;
