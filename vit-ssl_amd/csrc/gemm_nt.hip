@@ -372,18 +372,17 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
         const int i = ig + ii;
         const long long m = m0 + wm * 128 + i * 16 + (lane & 15);
         const bool okm = m < p.M;
+        u32x2 out_a[2][2], out_b[2][2];   // bf16 images of this row, both pairs: stored together below
   #pragma unroll
         for (int jp = 0; jp < 2; ++jp) {
           f32x4 v[2] = {acc[2 * jp][i] + bias4[jp][0], acc[2 * jp + 1][i] + bias4[jp][1]};
 
           if constexpr (EPI == VITSSL_EPI_BF16) {
-            const u32x2 w0 = {pack_bf2(v[0][0], v[0][1]), pack_bf2(v[0][2], v[0][3])};
-            const u32x2 w1 = {pack_bf2(v[1][0], v[1][1]), pack_bf2(v[1][2], v[1][3])};
-            store_bf16_pair(rsOut0, i, jp, w0, w1);
+            out_a[jp][0] = u32x2{pack_bf2(v[0][0], v[0][1]), pack_bf2(v[0][2], v[0][3])};
+            out_a[jp][1] = u32x2{pack_bf2(v[1][0], v[1][1]), pack_bf2(v[1][2], v[1][3])};
           } else if constexpr (EPI == VITSSL_EPI_GELU) {
             // u = bf16(acc + bias) (never stored); out1 = a = keep*scale*gelu(u) feeds the next
             // GEMM; out0 = g' = keep*scale*gelu'(u) is what the backward dGELU epilogue needs.
-            u32x2 gp[2], a[2];
   #pragma unroll
             for (int h = 0; h < 2; ++h) {
               float mult[4] = {1.f, 1.f, 1.f, 1.f};
@@ -395,14 +394,11 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
                 y[r] *= mult[r];
                 d[r] *= mult[r];
               }
-              a[h] = u32x2{pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
-              gp[h] = u32x2{pack_bf2(d[0], d[1]), pack_bf2(d[2], d[3])};
+              out_b[jp][h] = u32x2{pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
+              out_a[jp][h] = u32x2{pack_bf2(d[0], d[1]), pack_bf2(d[2], d[3])};
             }
-            store_bf16_pair(rsOut0, i, jp, gp[0], gp[1]);
-            store_bf16_pair(rsOut1, i, jp, a[0], a[1]);
           } else if constexpr (EPI == VITSSL_EPI_DGELU) {
             // du = acc * g'  (g' already carries the dropout mask and its scale)
-            u32x2 w[2];
   #pragma unroll
             for (int h = 0; h < 2; ++h) {
               const u32x2 gpv = gpre[ii][jp][h];
@@ -410,9 +406,8 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
               v[h][1] *= bf_hi(gpv[0]);
               v[h][2] *= bf_lo(gpv[1]);
               v[h][3] *= bf_hi(gpv[1]);
-              w[h] = u32x2{pack_bf2(v[h][0], v[h][1]), pack_bf2(v[h][2], v[h][3])};
+              out_a[jp][h] = u32x2{pack_bf2(v[h][0], v[h][1]), pack_bf2(v[h][2], v[h][3])};
             }
-            store_bf16_pair(rsOut0, i, jp, w[0], w[1]);
           } else if constexpr (EPI == EPI_F32_SPLITK) {
   #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -456,6 +451,15 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
                 for (int r = 0; r < 4; ++r) csum[2 * jp + h][r] += v[h][r];
               }
           }
+        }
+        // the row's 128 bytes of every bf16 image leave in back-to-back instructions
+        if constexpr (EPI == VITSSL_EPI_BF16 || EPI == VITSSL_EPI_GELU || EPI == VITSSL_EPI_DGELU) {
+          store_bf16_pair(rsOut0, i, 0, out_a[0][0], out_a[0][1]);
+          store_bf16_pair(rsOut0, i, 1, out_a[1][0], out_a[1][1]);
+        }
+        if constexpr (EPI == VITSSL_EPI_GELU) {
+          store_bf16_pair(rsOut1, i, 0, out_b[0][0], out_b[0][1]);
+          store_bf16_pair(rsOut1, i, 1, out_b[1][0], out_b[1][1]);
         }
       }
     }
