@@ -97,6 +97,20 @@ __device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 
+// One 128-byte row of 64 bf16 outputs.  A lane holds columns 16 dt + 4g .. +3 of the tiles
+// dt = 2p, 2p+1; exchanging halves between lane rows (g, g^1) with v_permlane16_swap gives every
+// lane 8 contiguous columns, i.e. one 16-byte store instead of two 8-byte ones (64-byte
+// segments per row per instruction; HBM writes are sensitive to this).
+// Both lanes of an exchanging pair share lane&15, so a row predicate on lane&15 is safe.
+__device__ __forceinline__ void store_row_pair16(bf16_t* row, int p, int g, const u32x2& w0, const u32x2& w1) {
+  auto lo = __builtin_amdgcn_permlane16_swap(w0[0], w1[0], false, false);
+  auto hi = __builtin_amdgcn_permlane16_swap(w0[1], w1[1], false, false);
+  const int odd = g & 1;
+  const u32x4 v = {lo[0], hi[0], lo[1], hi[1]};
+  *(u32x4*)(row + (2 * p + odd) * 16 + 4 * (g - odd)) = v;
+}
+__device__ __forceinline__ u32x2 pack4(const f32x4& o) { return u32x2{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])}; }
+
 // ------------------------------------------------------------------ forward
 // Softmax VALU budget.  The kernels are VALU-bound, not MFMA-bound (rocprofv3 PMC, forward:
 // 13.9 VALU instructions per score element against 1/14 MFMA), so every per-element
@@ -264,11 +278,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
       if (q[t] < N) {
         bf16_t* og = out + ((long long)b * N + q[t]) * (H * DH) + h * DH;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          const f32x4 o = (t == 0 ? o0[dt] : o1[dt]) * inv[t];
-          u32x2 w = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
-          *(u32x2*)(og + dt * 16 + 4 * g) = w;
-        }
+        for (int pr = 0; pr < 2; ++pr)
+          store_row_pair16(og, pr, g, pack4((t == 0 ? o0[2 * pr] : o1[2 * pr]) * inv[t]),
+                           pack4((t == 0 ? o0[2 * pr + 1] : o1[2 * pr + 1]) * inv[t]));
       }
     }
   }
@@ -676,13 +688,11 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16_t* __res
       if (key < N) {
         bf16_t* dkg = dqkv + ((long long)b * N + key) * stride + (long long)H * DH + h * DH;
         bf16_t* dvg = dkg + (long long)H * DH;
+        // each tensor's 128-byte row leaves in two back-to-back 16-byte-per-lane stores
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          u32x2 wk = {pack_bf2(dk[dt][kt][0], dk[dt][kt][1]), pack_bf2(dk[dt][kt][2], dk[dt][kt][3])};
-          u32x2 wv = {pack_bf2(dv[dt][kt][0], dv[dt][kt][1]), pack_bf2(dv[dt][kt][2], dv[dt][kt][3])};
-          *(u32x2*)(dkg + dt * 16 + 4 * g) = wk;
-          *(u32x2*)(dvg + dt * 16 + 4 * g) = wv;
-        }
+        for (int pr = 0; pr < 2; ++pr) store_row_pair16(dkg, pr, g, pack4(dk[2 * pr][kt]), pack4(dk[2 * pr + 1][kt]));
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) store_row_pair16(dvg, pr, g, pack4(dv[2 * pr][kt]), pack4(dv[2 * pr + 1][kt]));
       }
     }
   }
