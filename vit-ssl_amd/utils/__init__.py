@@ -3,4 +3,4 @@ model factory, optimizer/criterion/scheduler factories and the trainers' step lo
 The reference's Logger / MetricHandler / TrainingHistory (rich TUI, ignite, torcheval,
 matplotlib) are out of scope and intentionally not mirrored."""
 from .model_builder import build_model, freeze_backbone, load_weights
-from .train_utils import make_criterion, make_optimizer, make_schedulers, setup_device
+from .train_utils import get_transforms, make_criterion, make_optimizer, make_schedulers, setup_device

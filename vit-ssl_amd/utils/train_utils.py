@@ -27,6 +27,17 @@ def _spec(config, *path):
     return cfg_get(node, "name"), dict(cfg_get(node, "params", default={}) or {})
 
 
+def get_transforms(config):
+    """`transforms:` section -> {name: recipe}.  The reference turns every list into a
+    torchvision Compose that runs per image on the CPU (utils/train_utils.py:54-68); here the
+    DINO view lists (`globals`, `locals`: crop, flip, jitter, grayscale, blur, ToTensor) become
+    `data.ViewSpec` recipes that `data.GPUMultiCrop` renders for a whole batch on the GPU.
+    Lists with other transforms are data-loader business outside this package and are rejected
+    by `ViewSpec.from_config`."""
+    from data import ViewSpec
+    return {name: ViewSpec.from_config(sequence) for name, sequence in dict(cfg_get(config, "transforms") or {}).items()}
+
+
 def setup_device():
     """The engine has no CPU path, so unlike the reference this refuses to hand out 'cpu'."""
     if not torch.cuda.is_available():
