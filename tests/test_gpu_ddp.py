@@ -138,3 +138,70 @@ def test_rccl_single_rank_side_stream_allreduce(tmp_path):
     p.start()
     p.join(300)
     assert p.exitcode == 0 and os.path.exists(tmp_path / "ok_rccl")
+
+
+def _dino_build(dev):
+    from vit_core.ssl.dino import DINOViT
+    torch.manual_seed(9)
+    return DINOViT(2, (3, 32, 32), 64, 8, 1, 128, 0.0, 256, 0.9).to(dev).train()
+
+
+def _dino_worker(rank, world, port, out_dir):
+    """DINO under data parallelism: the centre update must use the GLOBAL teacher batch mean
+    (all-reduced column sums), the student gradient is averaged, teacher EMA stays local."""
+    for p in (ROOT, os.path.join(ROOT, "vit-ssl_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from _util import rel_l2
+        from vit_core.ssl.dino.loss import DINOLoss
+        from vitssl_hip.engine import GradReducer
+        from vitssl_hip.optim import FusedAdamW
+        dev = torch.device("cuda:0")
+        g = torch.Generator().manual_seed(4)
+        B = 4
+        views = [torch.rand(B, 3, 32, 32, generator=g).to(dev) for _ in range(2)] + [torch.rand(B, 3, 16, 16, generator=g).to(dev) for _ in range(2)]
+        per = B // world
+        sl = slice(rank * per, (rank + 1) * per)
+        crit = DINOLoss(0.04, 0.1)
+
+        model = _dino_build(dev)
+        store = model.trainable_store()
+        for s in model.all_stores():
+            dist.broadcast(s.flat, 0)
+            s.mark_dirty()
+        red = GradReducer(store.gflat, bucket_mb=0.25)
+        opt = FusedAdamW(store, lr=1e-3, weight_decay=1e-3)
+        loss = model.train_step([v[sl] for v in views], 2, crit, opt, red, 0.99)
+        torch.cuda.synchronize()
+        centers = [torch.empty_like(model.center) for _ in range(world)]
+        dist.all_gather(centers, model.center)
+        assert torch.equal(centers[0], centers[1])                      # one centre everywhere
+        flats = [torch.empty_like(store.flat) for _ in range(world)]
+        dist.all_gather(flats, store.flat)
+        assert torch.equal(flats[0], flats[1])                          # replicas stay identical
+        losses = [torch.zeros(1, device=dev) for _ in range(world)]
+        dist.all_gather(losses, loss.reshape(1))
+        grads = store.gflat * red.grad_scale
+        # reference: the whole batch in one model.  Both ranks run it (the centre update
+        # all-reduces whenever a process group exists; two identical contributions over
+        # 2 x rows give the same mean), rank 0 compares.
+        ref = _dino_build(dev)
+        rstore = ref.trainable_store()
+        ropt = FusedAdamW(rstore, lr=1e-3, weight_decay=1e-3)
+        rloss = ref.train_step(views, 2, crit, ropt, None, 0.99)
+        torch.cuda.synchronize()
+        if rank == 0:
+            assert rel_l2(model.center, ref.center) < 1e-5              # global teacher mean
+            assert abs(float(sum(losses)) / world - float(rloss)) < 2e-3 * abs(float(rloss)) + 1e-6
+            assert rel_l2(grads, rstore.gflat) < 3e-2
+        open(os.path.join(out_dir, f"dino_ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dino_two_ranks_share_one_centre(tmp_path):
+    world = 2
+    mp.spawn(_dino_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"dino_ok{r}").exists() for r in range(world))
