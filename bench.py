@@ -60,6 +60,17 @@ def pmc_traffic_per_launch(family="gemm_nt"):
         return None, None
 
 
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(cfg, img, P, ratio, seconds_budget=25.0):
     """Reference-equivalent fp32 CPU step (oracle/vit_oracle.py: zero_grad -> forward ->
     L1 -> backward -> AdamW, eager, dropout 0.1) on a bounded sample."""
@@ -90,7 +101,7 @@ def cpu_baseline(cfg, img, P, ratio, seconds_budget=25.0):
             break
     times.sort()
     med = times[len(times) // 2]
-    return {"value": round(Bc / med, 3), "unit": "images/s", "cores": cores, "kind": "port",
+    return {"value": round(Bc / med, 3), "unit": "images/s", "cores": cores, "cpu": _cpu_model(), "kind": "port",
             "sample": f"same model/inputs shape, batch {Bc}, {len(times)} measured step(s) after 1 warm-up, fp32 eager, dropout 0.1, AdamW"}
 
 
