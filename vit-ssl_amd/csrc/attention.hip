@@ -523,8 +523,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 // contract over ALL keys from that image -- S and dP are computed once instead of twice,
 // Q / K / V / dO are read from HBM once, there are no atomics and no N^2 traffic.
 // delta = rowsum(dO * O) is computed in the prologue.
-template <int NS>
-__global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ outp,
+// NW = waves per workgroup: 8 for long sequences; 4 when NS <= 4 (every key owner still gets
+// a wave, each wave then takes two dQ tiles per step) so that two workgroups share a CU --
+// DINO's 96x96 local crops are 37 tokens, and an 8-wave workgroup with six idle waves per
+// (batch, head) was launch-bound (5.8 us per workgroup, as long as a 197-token one).
+template <int NS, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ outp,
                                                              const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                              bf16_t* __restrict__ dqkv, int N, int H) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -549,8 +553,8 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16_t* __res
   const bool has_keys = wave < NS;      // wave-uniform; such a wave has at least one key < N
 
   // ---- prologue: delta / lse rows, own K / V fragments, then the three LDS tiles
-  {
-    const int row = threadIdx.x >> 1, half = threadIdx.x & 1;   // 2 threads per query row (Np <= 256)
+  for (int row = threadIdx.x >> 1; row < Np; row += 32 * NW) {   // 2 threads per query row
+    const int half = threadIdx.x & 1;
     float part = 0.f;
     if (row < N) {
 #pragma unroll
@@ -583,9 +587,9 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16_t* __res
       }
     }
   }
-  dma_tile<8>(Qt, qg, stride, N, Np, wave, lane);
-  dma_tile<8>(Dt, dog, ostride, N, Np, wave, lane);
-  dma_tile<8>(Kt, kg, stride, N, Np, wave, lane);
+  dma_tile<NW>(Qt, qg, stride, N, Np, wave, lane);
+  dma_tile<NW>(Dt, dog, ostride, N, Np, wave, lane);
+  dma_tile<NW>(Kt, kg, stride, N, Np, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -598,12 +602,10 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16_t* __res
       dv[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
       dk[dt][kt] = dv[dt][kt];
     }
-  const int qt_w = wave >> 2, dt_w = wave & 3;     // this wave's dQ tile inside a 32-query step
-
-  // dQ^T[d][q] = sum_key K[key][d] dS[q][key] for q-tile qt_w, columns 16 dt_w .. +15 of
-  // the 32 queries of step `qs`, from exchange image `sx`.  Two accumulators halve the
-  // dependent-MFMA chain.
-  auto dq_tile = [&](const char* sx, int qs) {
+  // dQ^T[d][q] = sum_key K[key][d] dS[q][key]: the 8 tiles (2 query tiles x 4 column slices) of
+  // a 32-query step are dealt round-robin to the NW waves (NW = 4: a wave gets both query
+  // tiles of one column slice).  Two accumulators halve the dependent-MFMA chain.
+  auto dq_one = [&](const char* sx, int qs, int qt_w, int dt_w) {
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
     const char* rowp = sx + (16 * qt_w + li) * SROW + 8 * g;
 #pragma unroll
@@ -620,6 +622,10 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const bf16_t* __res
       const u32x2 w = {pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3])};
       *(u32x2*)(dqkv + ((long long)b * N + q) * stride + h * DH + dt_w * 16 + 4 * g) = w;
     }
+  };
+  auto dq_tile = [&](const char* sx, int qs) {
+#pragma unroll
+    for (int tile = 0; tile < 8; tile += NW) dq_one(sx, qs, (wave + tile) >> 2, (wave + tile) & 3);
   };
 
   // Software pipeline: the dQ tile of step qs-1 (independent MFMAs and LDS reads) is issued
@@ -736,9 +742,10 @@ int launch_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const f
                int N, int H, hipStream_t s) {
   if (!attn_bwd_split()) {
     static bool done_f = false;
+    constexpr int NW = NS <= 2 ? 2 : (NS <= 4 ? 4 : 8);
     const int lds_f = 3 * NS * 32 * ROWB + 2 * 32 * (NS * 64 + 16) + 2 * NS * 32 * 4;
-    if (int rc = ensure_lds(attn_bwd_fused_kernel<NS>, lds_f, &done_f, "attn_bwd_fused")) return rc;
-    hipLaunchKernelGGL(attn_bwd_fused_kernel<NS>, dim3(B * H), dim3(512), lds_f, s, qkv, out, dout, lse, dqkv, N, H);
+    if (int rc = ensure_lds(attn_bwd_fused_kernel<NS, NW>, lds_f, &done_f, "attn_bwd_fused")) return rc;
+    hipLaunchKernelGGL((attn_bwd_fused_kernel<NS, NW>), dim3(B * H), dim3(64 * NW), lds_f, s, qkv, out, dout, lse, dqkv, N, H);
     VS_CHECK_LAUNCH("attn_bwd_fused");
     return VITSSL_OK;
   }
