@@ -39,10 +39,12 @@ namespace {
 template <int V>
 using IC = std::integral_constant<int, V>;
 
-template <int BK_, int WM_, int WN_>
+template <int BK_, int WM_, int WN_, int MI_ = 8>
 struct NtCfg {
   static constexpr int BK = BK_, WM = WM_, WN = WN_;
-  static constexpr int BM = 128 * WM_, BN = 64 * WN_;
+  static constexpr int MI = MI_;                              // 16-row MFMA tiles per wave along M
+  static constexpr int WROWS = 16 * MI_;                      // rows per wave
+  static constexpr int BM = WROWS * WM_, BN = 64 * WN_;
   static constexpr int WAVES = WM_ * WN_, THREADS = 64 * WM_ * WN_;
   static constexpr int ROWB = BK_ * 2;                       // bytes per tile row
   static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
@@ -53,6 +55,8 @@ struct NtCfg {
 };
 using NtBig = NtCfg<64, 2, 4>;
 using NtSmall = NtCfg<32, 2, 2>;
+// 192x256x64: for row counts whose 256-row tiling is "a round and a bit" (see launch_nt)
+using NtBig192 = NtCfg<64, 2, 4, 6>;
 
 struct NtParams {
   const bf16_t* A;
@@ -158,23 +162,24 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
   const int frag_row = lane & 15;
   const int kq = lane >> 4;
 
-  f32x4 acc[4][8];
+  constexpr int MI = CFG::MI;
+  f32x4 acc[4][MI];
 
   auto compute_stage = [&](const char* bufA, const char* bufB) {
 #pragma unroll
     for (int kk = 0; kk < BK / 32; ++kk) {
       const int coff = ((kk * 4 + kq) ^ swz) << 4;
-      bf16x8 fb[4], fa[8];
+      bf16x8 fb[4], fa[MI];
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         fb[j] = *(const bf16x8*)(bufB + (wn * 64 + j * 16 + frag_row) * CFG::ROWB + coff);
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        fa[i] = *(const bf16x8*)(bufA + (wm * 128 + i * 16 + frag_row) * CFG::ROWB + coff);
+      for (int i = 0; i < MI; ++i)
+        fa[i] = *(const bf16x8*)(bufA + (wm * CFG::WROWS + i * 16 + frag_row) * CFG::ROWB + coff);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < MI; ++i)
           acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
     }
   };
@@ -183,18 +188,18 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
   auto compute_half = [&](const char* bufA, const char* bufB, auto kk_c) {
     constexpr int kk = decltype(kk_c)::value;
     const int coff = ((kk * 4 + kq) ^ swz) << 4;
-    bf16x8 fb[4], fa[8];
+    bf16x8 fb[4], fa[MI];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       fb[j] = *(const bf16x8*)(bufB + (wn * 64 + j * 16 + frag_row) * CFG::ROWB + coff);
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      fa[i] = *(const bf16x8*)(bufA + (wm * 128 + i * 16 + frag_row) * CFG::ROWB + coff);
+    for (int i = 0; i < MI; ++i)
+      fa[i] = *(const bf16x8*)(bufA + (wm * CFG::WROWS + i * 16 + frag_row) * CFG::ROWB + coff);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < MI; ++i)
         acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
   };
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int t = 0; t < nk; ++t) {
       char* bufA = smem + par * CFG::BUF_BYTES;
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
       const unsigned rec = bytes > 0x80000000ull ? 0x80000000u : (unsigned)bytes;
       return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)base + m0 * p.N * elt), 0, (int)rec, 0x00020000);
     };
-    const unsigned row_l = (unsigned)(wm * 128 + (lane & 15));      // + 16 i : row inside the tile
+    const unsigned row_l = (unsigned)(wm * CFG::WROWS + (lane & 15));      // + 16 i : row inside the tile
     const unsigned un = (unsigned)p.N;
     const int odd = g4 & 1;
 
@@ -326,9 +331,10 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
     // (pair-major order left them half an epilogue apart and the second bf16 image of the GELU
     // epilogue was written at ~3 TB/s).  The residual / g' operands of a whole group are
     // loaded before its first use.
-    constexpr int RG = (EPI == VITSSL_EPI_RESID) ? 2 : 4;
+    constexpr int RG = (EPI == VITSSL_EPI_RESID || MI % 4 != 0) ? 2 : 4;
+    static_assert(MI % RG == 0, "row groups must tile the wave's rows");
   #pragma unroll
-    for (int ig = 0; ig < 8; ig += RG) {
+    for (int ig = 0; ig < MI; ig += RG) {
       f32x4 res[RG][2][2];     // RESID: residual stream
       u32x2 gpre[RG][2][2];    // DGELU: g' in accumulator layout
       if constexpr (EPI == VITSSL_EPI_RESID) {
@@ -370,7 +376,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
   #pragma unroll
       for (int ii = 0; ii < RG; ++ii) {
         const int i = ig + ii;
-        const long long m = m0 + wm * 128 + i * 16 + (lane & 15);
+        const long long m = m0 + wm * CFG::WROWS + i * 16 + (lane & 15);
         const bool okm = m < p.M;
         u32x2 out_a[2][2], out_b[2][2];   // bf16 images of this row, both pairs: stored together below
   #pragma unroll
@@ -547,7 +553,7 @@ int launch_cfg(NtParams p, hipStream_t s) {
   return VITSSL_OK;
 }
 
-// 0 = auto, 1 = always BIG, 2 = always SMALL (VITSSL_NT_TILE, developer knob)
+// 0 = auto, 1 = always BIG, 2 = always SMALL, 3 = always 192x256 (VITSSL_NT_TILE, developer knob)
 int nt_tile_override() {
   static int v = -1;
   if (v < 0) {
@@ -592,12 +598,23 @@ int launch_nt(const NtParams& p, hipStream_t s) {
   const int mode = nt_tile_override();
   if (mode == 1) return launch_cfg<EPI, NtBig>(p, s);
   if (mode == 2) return launch_cfg<EPI, NtSmall>(p, s);
+  if (mode == 3) return launch_cfg<EPI, NtBig192>(p, s);
   // Measured on MI355X (tools/bench_gemm.py, round 1): SMALL loses 10-25 % on every ViT-B
   // shape, heavy epilogues included; it only pays for grids too small to fill the chip.
   const long long big_tiles = ceil_div64(p.M, 256) * ceil_div64(p.N, 256);
   if (big_tiles < 64) return launch_cfg<EPI, NtSmall>(p, s);
   // (N = 384, ViT-S: three exact 128-wide SMALL columns instead of two 256-wide ones with the
   // second half empty were measured too: 21.1 vs 20.9 ms per step, not worth it.)
+  //
+  // Row counts whose 256-row tiling is "one round and a bit" (DINO global crops: M = 25216,
+  // N = 768 -> 297 tiles = 2 rounds for 1.16 rounds of work) are re-tiled with 192-row tiles
+  // when that needs fewer tile-rounds: cost model = rounds x (1 for 256x256, 0.78 for 192x256,
+  // measured ratio of the two main loops).
+  const long long slots = cu_count();
+  const long long tn = ceil_div64(p.N, 256);
+  const double c256 = (double)ceil_div64(ceil_div64(p.M, 256) * tn, slots);
+  const double c192 = 0.78 * (double)ceil_div64(ceil_div64(p.M, 192) * tn, slots);
+  if (c192 < 0.9 * c256) return launch_cfg<EPI, NtBig192>(p, s);
   return launch_cfg<EPI, NtBig>(p, s);
 }
 
