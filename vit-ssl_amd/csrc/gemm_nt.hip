@@ -55,7 +55,9 @@ struct NtCfg {
 };
 using NtBig = NtCfg<64, 2, 4>;
 using NtSmall = NtCfg<32, 2, 2>;
-// 192x256x64: for row counts whose 256-row tiling is "a round and a bit" (see launch_nt)
+// 224x256x64 and 192x256x64: fewer rows per tile when that needs fewer tile-rounds of the 256
+// CUs than the 256-row tiling (see launch_nt)
+using NtBig224 = NtCfg<64, 2, 4, 7>;
 using NtBig192 = NtCfg<64, 2, 4, 6>;
 
 struct NtParams {
@@ -95,11 +97,11 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* ld
   constexpr int RPI = 1024 / ROWB;              // tile rows per 1-KiB wave-instruction
   constexpr int LPR = ROWB / 16;                // lanes per row
   constexpr int SLOTS = ROWS / RPI;
-  static_assert(SLOTS % WAVES == 0, "tile rows must split evenly over the waves");
-  constexpr int PER = SLOTS / WAVES;
+  constexpr int PER = (SLOTS + WAVES - 1) / WAVES;   // uneven for 224-row tiles: the last wave issues fewer
 #pragma unroll
   for (int j = 0; j < PER; ++j) {
     const int i = wave * PER + j;               // wave-uniform instruction slot
+    if (SLOTS % WAVES != 0 && i >= SLOTS) break;
     const int r = i * RPI + lane / LPR;         // tile row this lane fetches for
     const int c = lane % LPR;                   // 16-B chunk position in the LDS row
     const int sc = c ^ nt_swz<BK_>(r);          // chunk fetched from global
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
     // (pair-major order left them half an epilogue apart and the second bf16 image of the GELU
     // epilogue was written at ~3 TB/s).  The residual / g' operands of a whole group are
     // loaded before its first use.
-    constexpr int RG = (EPI == VITSSL_EPI_RESID || MI % 4 != 0) ? 2 : 4;
+    constexpr int RG = MI % 2 != 0 ? 1 : ((EPI == VITSSL_EPI_RESID || MI % 4 != 0) ? 2 : 4);
     static_assert(MI % RG == 0, "row groups must tile the wave's rows");
   #pragma unroll
     for (int ig = 0; ig < MI; ig += RG) {
@@ -599,6 +601,7 @@ int launch_nt(const NtParams& p, hipStream_t s) {
   if (mode == 1) return launch_cfg<EPI, NtBig>(p, s);
   if (mode == 2) return launch_cfg<EPI, NtSmall>(p, s);
   if (mode == 3) return launch_cfg<EPI, NtBig192>(p, s);
+  if (mode == 4) return launch_cfg<EPI, NtBig224>(p, s);
   // Measured on MI355X (tools/bench_gemm.py, round 1): SMALL loses 10-25 % on every ViT-B
   // shape, heavy epilogues included; it only pays for grids too small to fill the chip.
   const long long big_tiles = ceil_div64(p.M, 256) * ceil_div64(p.N, 256);
@@ -613,8 +616,10 @@ int launch_nt(const NtParams& p, hipStream_t s) {
   const long long slots = cu_count();
   const long long tn = ceil_div64(p.N, 256);
   const double c256 = (double)ceil_div64(ceil_div64(p.M, 256) * tn, slots);
+  const double c224 = 0.90 * (double)ceil_div64(ceil_div64(p.M, 224) * tn, slots);
   const double c192 = 0.78 * (double)ceil_div64(ceil_div64(p.M, 192) * tn, slots);
-  if (c192 < 0.9 * c256) return launch_cfg<EPI, NtBig192>(p, s);
+  if (c192 < 0.9 * c256 && c192 <= c224) return launch_cfg<EPI, NtBig192>(p, s);
+  if (c224 < 0.95 * c256) return launch_cfg<EPI, NtBig224>(p, s);
   return launch_cfg<EPI, NtBig>(p, s);
 }
 
