@@ -161,11 +161,13 @@ __device__ __forceinline__ void softmax_tile(f32x4 (&s)[NKT], float& m_out, floa
   sum_out = sum;
 }
 
-// grid = B*H, 256 threads (2 workgroups per CU).  NS = number of 32-key steps
-// (Np = 32*NS >= N).  Each wave processes PAIRS of 16-query tiles so that every K / V
-// fragment read from LDS feeds two MFMAs.
-template <int NS>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+// grid = B*H, NW waves per workgroup: 4 (two workgroups per CU) for long sequences, 2 when
+// NS <= 2 (a 37-token DINO local crop has two query pairs: two of four waves would idle and
+// more, smaller workgroups share a CU).  NS = number of 32-key steps (Np = 32*NS >= N).
+// Each wave processes PAIRS of 16-query tiles so that every K / V fragment read from LDS
+// feeds two MFMAs.
+template <int NS, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                           float* __restrict__ lse, float* __restrict__ probs, int N, int H) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int Np = 32 * NS;
@@ -194,14 +196,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     qn[t][0] = glb_frag(qg, stride, wave * 32 + t * 16 + li, 0, N, lane);
     qn[t][1] = glb_frag(qg, stride, wave * 32 + t * 16 + li, 1, N, lane);
   }
-  dma_tile<4>(Kt, kg, stride, N, Np, wave, lane);
+  dma_tile<NW>(Kt, kg, stride, N, Np, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  dma_tile<4>(Vt, vg, stride, N, Np, wave, lane);
+  dma_tile<NW>(Vt, vg, stride, N, Np, wave, lane);
 
-  const int iters = (nqp + 3) >> 2;   // same trip count for every wave (uniform barriers)
+  const int iters = (nqp + NW - 1) / NW;   // same trip count for every wave (uniform barriers)
   for (int it = 0; it < iters; ++it) {
-    const int qp = wave + 4 * it;
+    const int qp = wave + NW * it;
     const bool active = qp < nqp;      // wave-uniform
     const int q[2] = {qp * 32 + li, qp * 32 + 16 + li};
     bf16x8 qf[2][2];
@@ -213,8 +215,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     if (it + 1 < iters) {              // software prefetch of the next pair's Q fragments
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        qn[t][0] = glb_frag(qg, stride, q[t] + 128, 0, N, lane);
-        qn[t][1] = glb_frag(qg, stride, q[t] + 128, 1, N, lane);
+        qn[t][0] = glb_frag(qg, stride, q[t] + 32 * NW, 0, N, lane);
+        qn[t][1] = glb_frag(qg, stride, q[t] + 32 * NW, 1, N, lane);
       }
     }
     f32x4 s0[NKT], s1[NKT];
@@ -721,8 +723,9 @@ template <int NS>
 int launch_fwd(const bf16_t* qkv, bf16_t* out, float* lse, float* probs, int B, int N, int H, hipStream_t s) {
   static bool done = false;
   const int lds = 2 * NS * 32 * ROWB;
-  if (int rc = ensure_lds(attn_fwd_kernel<NS>, lds, &done, "attn_fwd")) return rc;
-  hipLaunchKernelGGL(attn_fwd_kernel<NS>, dim3(B * H), dim3(256), lds, s, qkv, out, lse, probs, N, H);
+  constexpr int NW = NS <= 2 ? 2 : 4;
+  if (int rc = ensure_lds(attn_fwd_kernel<NS, NW>, lds, &done, "attn_fwd")) return rc;
+  hipLaunchKernelGGL((attn_fwd_kernel<NS, NW>), dim3(B * H), dim3(64 * NW), lds, s, qkv, out, lse, probs, N, H);
   VS_CHECK_LAUNCH("attn_fwd");
   return VITSSL_OK;
 }
