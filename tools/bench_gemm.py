@@ -35,7 +35,10 @@ def main():
     rb = lambda *s: (torch.randn(*s, device=DEV) * 0.5).to(torch.bfloat16)  # noqa: E731
     which = sys.argv[1:] or ["nt", "tn", "attn"]
     if "nt" in which:
-        for (N, K) in [(768, 768), (3072, 768), (768, 3072)]:
+        shapes = [(768, 768), (3072, 768), (768, 3072)]
+        if os.environ.get("EXTRA"):
+            shapes = [(2304, 768), (768, 2304)]
+        for (N, K) in shapes:
             A, B = rb(M, K), rb(N, K)
             bias = torch.randn(N, device=DEV)
             o16 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
