@@ -115,7 +115,8 @@ def _ref_acc(A, B):
 
 @pytest.mark.parametrize("M,N,K", [(300, 192, 64), (544, 768, 192), (1000, 260, 128), (257, 2304, 768), (37, 12, 64),
                                    (66000, 512, 128),      # 516 tiles, K <= 512: persistent workgroups, 3 tiles each
-                                   (25216, 768, 64)])      # 297 tiles: the 192-row tile variant
+                                   (25216, 768, 64),       # 297 tiles: the 192-row tile variant
+                                   (50000, 768, 64)])      # 588 tiles: the 224-row tile variant (uneven DMA split)
 def test_gemm_nt_epilogues(ops, M, N, K):
     from vitssl_hip import _lib as L
     torch.manual_seed(M + N + K)
