@@ -17,6 +17,8 @@ DEV = torch.device("cuda:0")
 CFGS = {
     "vit_s_simmim_b256": dict(D=384, L=12, H=6, F=1536, B=256),     # BASELINE configs[1]
     "vit_b_simmim_b64": dict(D=768, L=12, H=12, F=3072, B=64),      # configs[2] model at a test-sized batch
+    "vit_b_simmim_b256": dict(D=768, L=12, H=12, F=3072, B=256),    # configs[2] exactly (the bench workload: M = 50176, 224-row tiles)
+    "vit_l_simmim_b32": dict(D=1024, L=24, H=16, F=4096, B=32),     # configs[4] model (bf16 operands), test-sized batch
 }
 
 
@@ -91,3 +93,65 @@ def test_dino_fullsize_step():
     assert abs(float(want) - float(loss)) < 2e-3 * abs(float(want))
     loss2 = model.train_step(views, 2, crit, opt, None, teacher_momentum=0.996)
     assert torch.isfinite(loss2)
+
+
+def test_vit_tiny_supervised_config1_matches_oracle():
+    """BASELINE configs[0]: ViT-Tiny/16 (192 / 12 blocks / 3 heads / 768) supervised, 64x64, batch 32,
+    CrossEntropy -- small enough for the CPU oracle: logits, loss and every gradient."""
+    from vit_core import ViT
+    from oracle import vit_oracle as O
+    torch.manual_seed(42)
+    model = ViT(num_classes=10, num_blocks=12, input_shape=(3, 64, 64), embed_dim=192, patch_size=16, num_heads=3,
+                mlp_dim=768, dropout=0.0)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV).train()
+    g = torch.Generator().manual_seed(42)
+    x = torch.rand(32, 3, 64, 64, generator=g)
+    labels = torch.randint(0, 10, (32,), generator=g)
+    logits = model(x.to(DEV))
+    assert logits.shape == (32, 10)
+    loss = torch.nn.functional.cross_entropy(logits, labels.to(DEV))
+    loss.backward()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    want = O.vit_forward(leaves, x, 16, 3, emu="bf16")
+    wl = O.cross_entropy_mean(want, labels)
+    wl.backward()
+    assert rel_l2(logits, want) < 1e-2 and abs(float(loss) - float(wl)) < 1e-2 * float(wl)
+    fp32 = O.vit_forward(sd, x, 16, 3)
+    assert rel_l2(logits, fp32) < 2e-2                                              # and vs the pure fp32 path
+    for k, p in model.named_parameters():
+        assert rel_l2(p.grad, leaves[k].grad) < 5e-2, (k, rel_l2(p.grad, leaves[k].grad))
+    model.eval()
+    with torch.no_grad():
+        a = model(x[:4].to(DEV))
+        b = torch.cat([model(x[i:i + 1].to(DEV)) for i in range(4)])
+    assert max_abs(a, b) < 1e-4
+
+
+def test_vit_l_shaped_blocks_match_oracle():
+    """ViT-L/16 geometry (D = 1024, 16 heads, F = 4096, N = 196) on two blocks and two images:
+    the shapes of configs[4] that no other oracle-checked case reaches."""
+    from vit_core.ssl.simmim import SimMIMViT
+    from vit_core.ssl.simmim.masking import draw_mask
+    from oracle import vit_oracle as O
+    torch.manual_seed(7)
+    model = SimMIMViT(num_blocks=2, input_shape=(3, 224, 224), embed_dim=1024, patch_size=16, num_heads=16, mlp_dim=4096,
+                      dropout=0.0, mask_ratio=0.6)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV).train()
+    x = torch.rand(2, 3, 224, 224, generator=torch.Generator().manual_seed(8))
+    torch.manual_seed(9)
+    pred, tgt = model(x.to(DEV))
+    loss = torch.nn.functional.l1_loss(pred, tgt)
+    loss.backward()
+    torch.manual_seed(9)
+    mask = draw_mask(2, 196, 0.6)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    pe, te = O.simmim_forward(leaves, x, mask, 16, 16, emu="bf16")
+    assert torch.equal(tgt.cpu(), te)
+    assert rel_l2(pred, pe) < 1e-2
+    wl = O.l1_loss_mean(pe, te)
+    wl.backward()
+    assert abs(float(loss) - float(wl)) < 1e-2 * float(wl)
+    for k, p in model.named_parameters():
+        assert rel_l2(p.grad, leaves[k].grad) < 5e-2, (k, rel_l2(p.grad, leaves[k].grad))

@@ -149,3 +149,119 @@ def test_factories():
     opt = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(2))], lr=1e-4)
     s = make_schedulers(cfg, opt, num_epochs=10, warmup_steps=20)
     assert s["main"].T_max == 8 and s["warmup"].warmup_steps == 20
+
+
+def test_mirror_packages_do_not_hide_reference_modules(tmp_path):
+    """`vit-ssl_amd/` in front of a reference checkout on PYTHONPATH:
+    utils.model_builder / utils.trainers / vit_core come from this package, while the modules it
+    does not replace (utils.schemas, utils.logger, data.data_builder -> .datasets: what the
+    reference's train.py:7-11 imports) still resolve to the checkout behind it."""
+    import subprocess
+    import sys
+    from conftest import PKG
+    ref = tmp_path / "fake_reference"
+    (ref / "utils" / "schemas" / "training_schemas").mkdir(parents=True)
+    (ref / "data").mkdir()
+    (ref / "utils" / "__init__.py").write_text("raise ImportError('the reference utils/__init__ must not run')\n")
+    (ref / "utils" / "model_builder.py").write_text("WHO = 'reference'\n")
+    (ref / "utils" / "logger.py").write_text("class Logger:\n    WHO = 'reference'\n")
+    (ref / "utils" / "schemas" / "__init__.py").write_text("")
+    (ref / "utils" / "schemas" / "training_schemas" / "__init__.py").write_text("class TrainConfig:\n    WHO = 'reference'\n")
+    (ref / "data" / "__init__.py").write_text("raise ImportError('the reference data/__init__ must not run')\n")
+    (ref / "data" / "datasets.py").write_text("class STL10Dataset:\n    WHO = 'reference'\n")
+    (ref / "data" / "data_builder.py").write_text("from .datasets import STL10Dataset\n\ndef prepare_dataloaders():\n    return STL10Dataset.WHO\n")
+    code = (
+        "from utils.model_builder import build_model\n"
+        "import utils.model_builder as mb, utils.trainers as tr, vit_core\n"
+        "from data.data_builder import prepare_dataloaders\n"
+        "from utils.schemas.training_schemas import TrainConfig\n"
+        "from utils.logger import Logger\n"
+        "from data import GPUMultiCrop\n"
+        "assert not hasattr(mb, 'WHO') and hasattr(tr, 'SimMIMTrainer')\n"
+        "assert prepare_dataloaders() == 'reference' and TrainConfig.WHO == 'reference' and Logger.WHO == 'reference'\n"
+        "print('ok', mb.__file__)\n")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([PKG, str(ref)]))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.startswith("ok") and PKG in r.stdout
+
+
+def test_dino_trainer_schedules_match_reference_trainer():
+    """Keys, horizon and evaluation point of the two DINO schedules as the reference trainer has
+    them (utils/trainers/dino_trainer.py:16-29,46,80) on the shipped configs/dino/training.yaml."""
+    from utils.trainers.dino_trainer import DINOTrainer
+    g = load_golden("dino_trainer_sched")
+    n = int(g["num_epochs"])
+    shipped = {"training": {"type": "dino", "student_temp": 0.1, "teacher_temp": 0.04, "teacher_temp_final": 0.07,
+                            "teacher_temp_scheduler": "cosine", "teacher_momentum_start": 0.996, "teacher_momentum_final": 1,
+                            "num_epochs": n}}
+    temp, mom = DINOTrainer.build_schedules(shipped, n)
+    assert DINOTrainer.teacher_temp0(shipped) == 0.04
+    for i, e in enumerate(g["epochs"]):
+        assert abs(temp.get_temp(int(e)) - g["temp_cos"][i]) < 1e-12
+        assert abs(mom.get_momentum(int(e)) - g["mom"][i]) < 1e-12
+    assert temp.get_temp(31) < 0.05 and abs(temp.get_temp(n) - 0.07) < 1e-12      # reaches 0.07 at epoch 100, not 31
+    lin = dict(shipped["training"], teacher_temp_scheduler="linear")
+    temp, _ = DINOTrainer.build_schedules({"training": lin}, n)
+    for i, e in enumerate(g["epochs"]):
+        assert abs(temp.get_temp(int(e)) - g["temp_lin"][i]) < 1e-12
+    const = {k: v for k, v in shipped["training"].items() if k != "teacher_temp_final"}
+    const["teacher_temp"] = 0.05                                                    # no final -> constant teacher_temp
+    temp, _ = DINOTrainer.build_schedules({"training": const}, n)
+    for i, e in enumerate(g["epochs"]):
+        assert abs(temp.get_temp(int(e)) - g["temp_const"][i]) < 1e-12
+
+
+def test_reference_written_checkpoint_loads_like_the_reference(tmp_path):
+    """tests/golden/ckpt_ref_simmim.pth was written by the REFERENCE (torch.compile wrapper ->
+    `_orig_mod.` keys, base_trainer.py:99-105 layout).  load_weights must put into a fine-tuning
+    ViT exactly what the reference's own load_weights puts there from the same tensors
+    (utils/model_builder.py:39-72), and the SimMIM model must take the state dict whole."""
+    from _util import GOLDEN
+    from utils.model_builder import load_weights, strip_compile_prefix
+    from vit_core import ViT
+    from vit_core.ssl.simmim import SimMIMViT
+    g = load_golden("ckpt_ref_expected")
+    B, img, patch, D, H, F, blocks, C = (int(v) for v in g["cfg"])
+    path = os.path.join(GOLDEN, "ckpt_ref_simmim.pth")
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(ckpt) == {"epoch", "model_state_dict", "optimizer_state_dict", "best_val_loss", "config"}
+    assert all(k.startswith("_orig_mod.") for k in ckpt["model_state_dict"])
+    vit = ViT(C, blocks, (3, img, img), D, patch, H, F, 0.0)
+    vit.load_state_dict(split_prefix(g, "vit_init/"))
+    load_weights(vit, path)
+    want = split_prefix(g, "vit_loaded/")
+    assert set(vit.state_dict()) == set(want)
+    for k, v in want.items():
+        assert torch.equal(vit.state_dict()[k], v), k
+    sim = SimMIMViT(blocks, (3, img, img), D, patch, H, F, 0.0, 0.6)
+    sim.load_state_dict(strip_compile_prefix(ckpt["model_state_dict"]), strict=True)
+    for k, v in split_prefix(g, "simmim/").items():
+        assert torch.equal(sim.state_dict()[k], v), k
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/vit_core"), reason="needs the reference checkout (build container only)")
+def test_checkpoint_written_here_loads_into_the_reference(tmp_path):
+    """The other direction: a trainer checkpoint of THIS package (same dict layout) is taken by
+    the reference modules' load_state_dict(strict=True).  Runs the reference in a subprocess."""
+    import subprocess
+    import sys
+    from vit_core.ssl.simmim import SimMIMViT
+    torch.manual_seed(5)
+    sim = SimMIMViT(2, (3, 32, 32), 64, 8, 2, 128, 0.1, 0.6)
+    path = os.path.join(tmp_path, "last_model.pth")
+    torch.save({"epoch": 1, "model_state_dict": sim.state_dict(), "optimizer_state_dict": {}, "config": {}}, path)
+    code = (
+        "import sys, torch\n"
+        "sys.path.insert(0, '/root/reference')\n"
+        "from vit_core.ssl.simmim.model import SimMIMViT\n"
+        "m = SimMIMViT(num_blocks=2, input_shape=(3, 32, 32), embed_dim=64, patch_size=8, num_heads=2, mlp_dim=128, dropout=0.1, mask_ratio=0.6)\n"
+        f"ck = torch.load({path!r}, map_location='cpu', weights_only=False)\n"
+        "r = m.load_state_dict(ck['model_state_dict'], strict=True)\n"
+        "assert not r.missing_keys and not r.unexpected_keys\n"
+        "print('ok', float(sum(p.double().sum() for p in m.parameters())))\n")
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    total = float(sum(p.double().sum() for p in sim.parameters()))
+    assert abs(float(r.stdout.split()[1]) - total) < 1e-9 * max(1.0, abs(total))

@@ -155,3 +155,63 @@ def test_adamw():
     for i in range(g["grads"].shape[0]):
         p, m, v = O.adamw_step(p, t(g["grads"][i]), m, v, i + 1, float(g["lr"]), wd=float(g["wd"]))
         assert max_abs(p, t(g["params"][i + 1])) < 1e-6
+
+
+def _unpack(g, key):
+    shape = tuple(int(v) for v in g[key + "_shape"])
+    n = int(np.prod(shape))
+    return torch.from_numpy(np.unpackbits(g[key])[:n].reshape(shape).astype(np.float32))
+
+
+def test_encoder_block_dropout_sites_match_reference():
+    """The three dropout sites of a block (vit_core/encoder_block.py:45-46,51-52,
+    feed_forward.py:27), their placement and their 1/(1-p) scaling: the reference ran with
+    dropout 0.1 in train mode and its own keep masks were captured (make_golden_r2.py)."""
+    g = load_golden("ops_drop")
+    p = float(g["p"])
+    keep = [_unpack(g, k) for k in ("keep1", "keep_inner", "keep2")]
+    assert 0.85 < float(keep[0].mean()) < 0.95
+    leaves = {k: v.clone().requires_grad_(True) for k, v in split_prefix(g, "sd/").items()}
+    x = t(g["x"]).clone().requires_grad_(True)
+    y, _ = O.encoder_block(x, leaves, "", 2, keep=keep, p_drop=p)
+    assert rel_l2(y, t(g["y"])) < TOL
+    y.square().sum().backward()
+    assert rel_l2(x.grad, t(g["dx"])) < 1e-4
+    for k, gr in split_prefix(g, "grad/").items():
+        assert rel_l2(leaves[k].grad, gr) < 1e-4, k
+    # and the masks matter: without them the oracle is far from the reference output
+    y0, _ = O.encoder_block(t(g["x"]), split_prefix(g, "sd/"), "", 2)
+    assert rel_l2(y0, t(g["y"])) > 1e-2
+
+
+def test_simmim_with_dropout_matches_reference():
+    g = load_golden("simmim_drop")
+    B, img, patch, D, H, F, blocks = (int(v) for v in g["cfg"])
+    x = t(g["x_u8"]).float() / 256.0
+    torch.manual_seed(int(g["mask_seed"]))
+    mask = O.simple_masking(B, (img // patch) ** 2, float(g["ratio"]))     # masking consumes the RNG first
+    assert np.array_equal(mask.numpy(), g["mask"])
+    keeps = [[_unpack(g, f"keep{i}_{j}") for j in range(3)] for i in range(blocks)]
+    leaves = {k: v.clone().requires_grad_(True) for k, v in split_prefix(g, "sd/").items()}
+    pred, tgt = O.simmim_forward(leaves, x, mask, patch, H, keeps=keeps, p_drop=float(g["p"]))
+    assert np.array_equal(tgt.numpy(), g["targets"])
+    assert rel_l2(pred, t(g["pred"])) < TOL
+    loss = O.l1_loss_mean(pred, tgt)
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-6
+    loss.backward()
+    for k, gr in split_prefix(g, "grad/").items():
+        assert rel_l2(leaves[k].grad, gr) < 2e-4, k
+
+
+def test_manual_patch_embedding_matches_reference():
+    """ManualPatchEmbedding (vit_core/patch_embedding.py:122-128) == unfold . Linear + CLS + pos."""
+    g = load_golden("manual_embed")
+    B, img, patch, D = (int(v) for v in g["cfg"])
+    x = t(g["x_u8"]).float() / 256.0
+    leaves = {k: v.clone().requires_grad_(True) for k, v in split_prefix(g, "sd/").items()}
+    y = O.conv_patch_embed(x, leaves["linear.weight"], leaves["linear.bias"], leaves["cls_token"],
+                           leaves["positional_embedding"], patch)
+    assert rel_l2(y, t(g["y"])) < TOL
+    (y * t(g["w"])).sum().backward()
+    for k, gr in split_prefix(g, "grad/").items():
+        assert rel_l2(leaves[k].grad, gr) < 1e-4, k

@@ -25,9 +25,36 @@ class DINOTrainer(BaseTrainer):
         super().__init__(*args, **kwargs)
         t = lambda k, d=None: cfg_get(self.config, "training", k, default=d)  # noqa: E731
         self.num_global_views = cfg_get(self.config, "data", "num_global_views", default=t("num_global_views", 2))
-        self.temp_sched = DINOTeacherTempScheduler(t("teacher_temp_start", 0.04), t("teacher_temp_final", 0.07),
-                                                   t("teacher_temp_warmup_epochs", 30))
-        self.mom_sched = DINOMomentumScheduler(t("teacher_momentum_start", 0.996), t("teacher_momentum_final", 1.0), self.num_epochs)
+        self.temp_sched, self.mom_sched = self.build_schedules(self.config, self.num_epochs)
+
+    @staticmethod
+    def teacher_temp0(config):
+        """`training.teacher_temp` (reference key); `teacher_temp_start` is accepted as the
+        spelling this package's round-1 configs used."""
+        temp0 = cfg_get(config, "training", "teacher_temp", default=None)
+        if temp0 is None:
+            temp0 = cfg_get(config, "training", "teacher_temp_start", default=0.04)
+        return temp0
+
+    @staticmethod
+    def build_schedules(config, num_epochs):
+        """(temperature, momentum) schedulers exactly as the reference trainer builds them
+        (utils/trainers/dino_trainer.py:16-29 with configs/dino/training.yaml): `teacher_temp` is
+        the start, `teacher_temp_final` defaults to it, BOTH run over num_epochs,
+        `teacher_temp_scheduler` picks cosine | linear.  They are evaluated at `epoch`, which
+        starts at 1 (reference :46, :80) -- see epoch_schedule."""
+        t = lambda k, d=None: cfg_get(config, "training", k, default=d)  # noqa: E731
+        temp0 = DINOTrainer.teacher_temp0(config)
+        temp1 = t("teacher_temp_final")
+        if temp1 is None:
+            temp1 = temp0
+        temp = DINOTeacherTempScheduler(temp0, temp1, num_epochs, t("teacher_temp_scheduler", "cosine"))
+        mom = DINOMomentumScheduler(t("teacher_momentum_start", 0.996), t("teacher_momentum_final", 1.0), num_epochs)
+        return temp, mom
+
+    def epoch_schedule(self, epoch: int):
+        """(teacher temperature, EMA momentum) of 1-based `epoch`."""
+        return self.temp_sched.get_temp(epoch), self.mom_sched.get_momentum(epoch)
 
     def _views(self, inputs):
         if isinstance(inputs, torch.Tensor) and inputs.dtype == torch.uint8 and inputs.dim() == 4:
@@ -42,7 +69,7 @@ class DINOTrainer(BaseTrainer):
 
     def create_criterion(self):
         t = lambda k, d=None: cfg_get(self.config, "training", k, default=d)  # noqa: E731
-        return DINOLoss(teacher_temp=t("teacher_temp_start", 0.04), student_temp=t("student_temp", 0.1))
+        return DINOLoss(teacher_temp=self.teacher_temp0(self.config), student_temp=t("student_temp", 0.1))
 
     def _loss(self, views):
         G = self.num_global_views
@@ -53,8 +80,7 @@ class DINOTrainer(BaseTrainer):
 
     def train_epoch(self, epoch: int):
         self.model.train()
-        self.criterion.teacher_temp = self.temp_sched.get_temp(epoch - 1)
-        momentum = self.mom_sched.get_momentum(epoch - 1)
+        self.criterion.teacher_temp, momentum = self.epoch_schedule(epoch)
         fused = self._is_fused()
         total, running = 0, None
         for idx, inputs in enumerate(self.train_loader):

@@ -51,9 +51,12 @@ class BackboneRuntime:
         T = tokens + 1
         dev = x.device
         pos, pos_graph = self.pos_for(gh, gw, need_grad=save)
-        patches = ws.get(f"{slot}.patches", (B * tokens, self.Pd), BF16, dev)
+        # a forward that saves nothing (no_grad / eval) must not touch the buffers a pending
+        # backward of the same slot still needs
+        wtag = slot if save else slot + ".tmp"
+        patches = ws.get(f"{wtag}.patches", (B * tokens, self.Pd), BF16, dev)
         ops.patchify_bf16(x, patches, self.P)
-        x0 = ws.get(f"{slot}.x0", (B * T, self.D), F32, dev)
+        x0 = ws.get(f"{wtag}.x0", (B * T, self.D), F32, dev)
         ops.gemm_nt(patches, st.w(self.wkey), x0, L.EPI_EMBED, bias=st.view(self.names["bias"]),
                     embed=(None, None, pos, tokens, T, 1))
         x0.view(B, T, self.D)[:, 0] = st.view(self.names["cls"]) + pos[0]

@@ -371,6 +371,7 @@ class _StackFn(Function):
         y, probs = runner.stack.forward(R.as_f32(x).reshape(Bn * T, D), Bn, T, training, seed, save=need, slot=slot,
                                         return_attn=return_attn)
         ctx.runner, ctx.slot, ctx.shape = runner, slot, (Bn, T, D)
+        ctx.gen = runner.stamp(slot) if need else 0
         y = y.view(Bn, T, D).clone()      # the stack's buffers are reused by the next call
         if return_attn:
             ctx.mark_non_differentiable(probs)
@@ -382,6 +383,7 @@ class _StackFn(Function):
         runner = ctx.runner
         Bn, T, D = ctx.shape
         st = runner.store
+        R.check_saved_generation("encoder stack", ctx.gen, runner.slot_gen.get(ctx.slot, -1))
         st.gflat.zero_()
         g = R.as_f32(dy).reshape(Bn * T, D).clone()
         g = runner.stack.backward(g, slot=ctx.slot)
@@ -399,6 +401,13 @@ class StackRunner:
         self.stack = R.EncoderStack(self.store, block_prefixes, D, H, Fd, p)
         self.device = device
         self._slots = 0
+        self._gen = 0
+        self.slot_gen = {}     # slot -> id of the forward whose activations it holds
+
+    def stamp(self, slot):
+        self._gen += 1
+        self.slot_gen[slot] = self._gen
+        return self._gen
 
     def valid_for(self, device) -> bool:
         return device == self.device and self.store.is_attached()

@@ -31,6 +31,17 @@ def next_seed() -> int:
     return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
 
 
+def check_saved_generation(who: str, graph_gen: int, live_gen: int):
+    """The engine keeps the activations of ONE grad-enabled forward per runtime (step-persistent
+    workspaces, not per-graph autograd storage).  A backward through an older graph would
+    silently use the newer forward's activations: refuse it."""
+    if graph_gen != live_gen:
+        raise L.VitsslError(
+            f"{who}: backward of forward #{graph_gen}, but a later grad-enabled forward (#{live_gen}) has replaced its "
+            "saved activations. Call backward() before the next training forward (or run the extra forward under "
+            "torch.no_grad()); gradient accumulation over micro-batches works as forward/backward pairs.")
+
+
 def as_f32(x: torch.Tensor) -> torch.Tensor:
     if x.dtype != F32:
         x = x.float()

@@ -44,18 +44,19 @@ class HeadRuntime:
         self.prepare()
         Rn = feats.shape[0]
         dev = feats.device
-        xb = ws.get(slot + ".xb", (Rn, self.D), BF16, dev)
+        tag = slot if save else slot + ".tmp"     # a no-save forward leaves a pending backward's buffers alone
+        xb = ws.get(tag + ".xb", (Rn, self.D), BF16, dev)
         ops.cast_bf16(R.as_f32(feats), xb)
-        u0 = ws.get(slot + ".u0", (Rn, self.Hd), BF16, dev)
-        a0 = ws.get(slot + ".a0", (Rn, self.Hd), BF16, dev)
+        u0 = ws.get(tag + ".u0", (Rn, self.Hd), BF16, dev)
+        a0 = ws.get(tag + ".a0", (Rn, self.Hd), BF16, dev)
         ops.gemm_nt(xb, st.w(p + "w0"), u0, L.EPI_GELU, bias=st.view(p + "mlp.0.bias"), out1=a0)
-        u1 = ws.get(slot + ".u1", (Rn, self.Hd), BF16, dev)
-        a1 = ws.get(slot + ".a1", (Rn, self.Hd), BF16, dev)
+        u1 = ws.get(tag + ".u1", (Rn, self.Hd), BF16, dev)
+        a1 = ws.get(tag + ".a1", (Rn, self.Hd), BF16, dev)
         ops.gemm_nt(a0, st.w(p + "w2"), u1, L.EPI_GELU, bias=st.view(p + "mlp.2.bias"), out1=a1)
-        z = ws.get(slot + ".z", (Rn, self.D), F32, dev)
+        z = ws.get(tag + ".z", (Rn, self.D), F32, dev)
         ops.gemm_nt(a1, st.w(p + "w4"), z, L.EPI_F32, bias=st.view(p + "mlp.4.bias"))
-        zn = ws.get(slot + ".zn", (Rn, self.D), BF16, dev)
-        inv = ws.get(slot + ".inv", (Rn,), F32, dev)
+        zn = ws.get(tag + ".zn", (Rn, self.D), BF16, dev)
+        inv = ws.get(tag + ".inv", (Rn,), F32, dev)
         ops.rownorm_fwd(z, zn, inv)
         ops.gemm_nt(zn, self.wn, out_logits, L.EPI_F32, bias=st.view(self.b_name))
         if save:

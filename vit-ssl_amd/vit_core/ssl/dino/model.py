@@ -63,6 +63,7 @@ class _DINORuntime:
             raise L.VitsslError("DINOViT: teacher and student parameter layouts differ")
         self.ws = R.Workspace()
         self.rec = None
+        self.save_gen = 0
 
     def valid_for(self, device):
         return device == self.device and all(s.is_attached() for s in self.stores.values())
@@ -88,6 +89,7 @@ class _DINORuntime:
         self.head["teacher"].forward(ft, teacher, save=False, slot="t")
         self.update_center(teacher)
         if save:
+            self.save_gen += 1
             self.rec = dict(G=G, V=V, B=B)
         return teacher, student
 
@@ -127,13 +129,14 @@ class _DINOFn(Function):
     @staticmethod
     def forward(ctx, rt, views, G, training, need, *params):
         teacher, student = rt.forward(list(views), G, training, save=need)
-        ctx.rt = rt
+        ctx.rt, ctx.gen = rt, rt.save_gen
         ctx.mark_non_differentiable(teacher)
         return teacher, student
 
     @staticmethod
     def backward(ctx, _dt, dstudent):
         rt = ctx.rt
+        R.check_saved_generation("DINOViT", ctx.gen, rt.save_gen)
         st = rt.stores["student"]
         st.gflat.zero_()
         d = R.as_f32(dstudent)

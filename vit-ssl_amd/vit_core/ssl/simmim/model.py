@@ -43,19 +43,22 @@ class _SimMIMRuntime:
         st.register_weight("head", lambda: st.view("simmim_head.weight", (self.Pd, self.D)))
         self.ws = R.Workspace()
         self.rec = None
+        self.save_gen = 0      # id of the forward whose activations `rec` / the stack hold
 
     def valid_for(self, device) -> bool:
         return device == self.device and self.store.is_attached()
 
     # ------------------------------------------------------------------ forward
-    def embed(self, x, mask_d):
-        """image -> encoder input tokens fp32 [B*N, D] (also leaves bf16 patches in ws)."""
+    def embed(self, x, mask_d, tag=""):
+        """image -> encoder input tokens fp32 [B*N, D] (also leaves bf16 patches in ws).
+        `tag` separates the buffers of forwards that save nothing from those a pending backward
+        still needs."""
         st, ws = self.store, self.ws
         B = x.shape[0]
         M = B * self.N
-        patches = ws.get("patches", (M, self.Pd), BF16, x.device)
+        patches = ws.get(tag + "patches", (M, self.Pd), BF16, x.device)
         ops.patchify_bf16(x, patches, self.P)
-        x0 = ws.get("x0", (M, self.D), F32, x.device)
+        x0 = ws.get(tag + "x0", (M, self.D), F32, x.device)
         ops.gemm_nt(patches, st.w("proj"), x0, L.EPI_EMBED, bias=st.view("projection.bias"),
                     embed=(mask_d, st.view("mask_token") if mask_d is not None else None,
                            st.view("positional_embedding", (self.N, self.D)), self.N, self.N, 0))
@@ -115,13 +118,15 @@ class _SimMIMRuntime:
 
         targets = torch.empty(Mm, self.Pd, dtype=F32, device=dev)
         ops.gather_patches_f32(x, idx_d, targets, self.P)
-        x0, patches = self.embed(x, mask_d)
+        tag = "" if save else "tmp."
+        x0, patches = self.embed(x, mask_d, tag)
         xL, _ = self.stack.forward(x0, B, self.N, training, seed, save=save, slot="a")
-        sel = ws.get("sel", (Mm, self.D), BF16, dev)
+        sel = ws.get(tag + "sel", (Mm, self.D), BF16, dev)
         ops.gather_rows_bf16(xL, idx_d, sel)
         pred = torch.empty(Mm, self.Pd, dtype=F32, device=dev)
         ops.gemm_nt(sel, st.w("head"), pred, L.EPI_F32, bias=st.view("simmim_head.bias"))
         if save:
+            self.save_gen += 1
             self.rec = dict(B=B, M=M, Mm=Mm, idx=idx_d, inv=inv_d, mask=mask_d, patches=patches, sel=sel)
         return pred, targets, mask_d.view(B, self.N, 1).bool()
 
@@ -155,13 +160,14 @@ class _SimMIMFn(Function):
     @staticmethod
     def forward(ctx, rt, x, training, need, *params):
         pred, targets, mask = rt.forward(x, training, save=need)
-        ctx.rt = rt
+        ctx.rt, ctx.gen = rt, rt.save_gen
         ctx.mark_non_differentiable(targets, mask)
         return pred, targets, mask
 
     @staticmethod
     def backward(ctx, dpred, _dt, _dm):
         rt = ctx.rt
+        R.check_saved_generation("SimMIMViT", ctx.gen, rt.save_gen)
         st = rt.store
         st.gflat.zero_()
         dp = R.as_f32(dpred)
@@ -236,7 +242,7 @@ class SimMIMViT(nn.Module):
         rt.store.refresh_weights()
         x = R.as_f32(x)
         B = x.shape[0]
-        x0, _ = rt.embed(x, None)
+        x0, _ = rt.embed(x, None, "inf.")
         xL, _ = rt.stack.forward(x0, B, rt.N, False, 0, save=False, slot="inf")
         feats = xL.view(B, rt.N, rt.D)
         return feats.clone() if return_patch_features else feats.mean(dim=1)

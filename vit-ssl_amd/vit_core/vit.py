@@ -30,6 +30,7 @@ class _ViTRuntime:
             len(model.encoder_blocks), C, P, (Hh // P, Ww // P), self.D, model.num_heads, model.mlp_dim, model.dropout_p)
         self.ncls = model.num_classes
         self.rec = None
+        self.save_gen = 0
 
     def valid_for(self, device):
         return device == self.device and self.store.is_attached()
@@ -62,6 +63,7 @@ class _ViTRuntime:
         logits = torch.empty(B, Nk, dtype=F32, device=dev)
         ops.gemm_nt(h, wb, logits, L.EPI_F32, bias=bias)
         if save:
+            self.save_gen += 1
             self.rec = dict(feats=feats, h=h, mean=mean, rstd=rstd, wt=wt, Nk=Nk, B=B)
         return logits[:, :self.ncls].contiguous(), probs
 
@@ -94,7 +96,7 @@ class _ViTFn(Function):
     @staticmethod
     def forward(ctx, rt, x, training, return_attn, need, *params):
         logits, probs = rt.forward(x, training, save=need, return_attn=return_attn)
-        ctx.rt = rt
+        ctx.rt, ctx.gen = rt, rt.save_gen
         if return_attn:
             ctx.mark_non_differentiable(probs)
             return logits, probs
@@ -103,6 +105,7 @@ class _ViTFn(Function):
     @staticmethod
     def backward(ctx, dlogits, _dp):
         rt = ctx.rt
+        R.check_saved_generation("ViT", ctx.gen, rt.save_gen)
         st = rt.store
         st.gflat.zero_()
         rt.backward(dlogits)

@@ -82,8 +82,7 @@ class FlatStore:
                 view.copy_(p.data)
                 p.data = view
         self._bf16: Dict[str, torch.Tensor] = {}
-        self._bf16_version = -1
-        self._dirty = True
+        self._bf16_key = None
         self.generation = 0   # bumped whenever the flat buffer is rewritten behind torch's back
         self._cast_jobs: List[Tuple[str, Callable[[], torch.Tensor], bool]] = []
 
@@ -127,11 +126,19 @@ class FlatStore:
             p.grad = self.gview(name, p.shape)
 
     def mark_dirty(self):
-        self._dirty = True
+        """Called by everything that rewrites the flat buffer through a raw pointer (the HIP
+        AdamW / EMA kernels, broadcasts): torch's version counters do not see those writes."""
         self.generation += 1
 
     def weights_key(self):
-        return (self.generation, self.flat._version)
+        """Changes whenever any parameter value may have changed.  `p.data = flat_view` gives
+        every Parameter its OWN version counter, so in-place updates through the Parameters
+        (any torch optimizer, load_state_dict, p.copy_ / p.mul_ ...) bump p._version and leave
+        flat._version alone: the key has to include both (about 150 integers per model)."""
+        pv = 0
+        for p in self.params:
+            pv += p._version
+        return (self.generation, self.flat._version, pv)
 
     # ---- bf16 weight caches --------------------------------------------------
     def register_weight(self, key: str, src: Callable[[], torch.Tensor], transposed_too: bool = True):
@@ -140,8 +147,8 @@ class FlatStore:
         self._cast_jobs.append((key, src, transposed_too))
 
     def refresh_weights(self):
-        ver = self.flat._version
-        if not self._dirty and ver == self._bf16_version and self._bf16:
+        key = self.weights_key()
+        if key == self._bf16_key and self._bf16:
             return
         jobs = []
         for key, src, tr in self._cast_jobs:
@@ -162,8 +169,7 @@ class FlatStore:
             if getattr(self, "_cast_plan", None) is None:
                 self._cast_plan = ops.CastPlan()
             self._cast_plan.run(jobs)
-        self._bf16_version = self.flat._version
-        self._dirty = False
+        self._bf16_key = key
 
     def w(self, key: str) -> torch.Tensor:
         return self._bf16[key]

@@ -21,6 +21,11 @@ def _chk(t, dtype, name, shape=None):
         raise L.VitsslError(f"{name}: tensor is None")
     if not t.is_cuda:
         raise L.VitsslError(f"{name}: expected a CUDA (HIP) tensor, got {t.device}; there is no CPU fallback")
+    if t.device.index != torch.cuda.current_device():
+        # launches go to the CURRENT device's current stream: a tensor of another GPU would be
+        # touched by a kernel enqueued on the wrong device
+        raise L.VitsslError(f"{name}: tensor lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}; "
+                            "call torch.cuda.set_device (one process per GPU) before using the engine")
     if t.dtype != dtype:
         raise L.VitsslError(f"{name}: expected dtype {dtype}, got {t.dtype}")
     if not t.is_contiguous():

@@ -36,7 +36,9 @@ class FusedAdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def step_flat(self, gscale: float = 1.0):
         if not self._all_trainable:
-            return self.step(gscale=gscale)
+            # frozen parameters in the store: per-parameter launches over the trainable slices.
+            # The fused step leaves its gradients in store.gflat only (p.grad stays None).
+            return self.step(gscale=gscale, from_flat=True)
         lr, b1, b2, eps, wd = self._hyper()
         self.step_count += 1
         st = self.store
@@ -44,7 +46,9 @@ class FusedAdamW(torch.optim.Optimizer):
         st.mark_dirty()
 
     @torch.no_grad()
-    def step(self, closure=None, gscale: float = 1.0):
+    def step(self, closure=None, gscale: float = 1.0, from_flat: bool = False):
+        """torch-style step.  `from_flat=True`: the gradients already live in the store's flat
+        gradient buffer (fused train_step), so p.grad is not consulted."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -54,11 +58,11 @@ class FusedAdamW(torch.optim.Optimizer):
         st = self.store
         trainable = {id(p) for p in self.param_groups[0]["params"]}
         for name, p in zip(st.names, st.params):
-            if id(p) not in trainable or p.grad is None:
+            if id(p) not in trainable or (p.grad is None and not from_flat):
                 continue
             o, n = st.offsets[name]
             gslice = st.gflat[o:o + n]
-            if p.grad.data_ptr() != gslice.data_ptr():
+            if not from_flat and p.grad.data_ptr() != gslice.data_ptr():
                 gslice.copy_(p.grad.reshape(-1))
             ops.adamw(st.flat[o:o + n], gslice, self.exp_avg[o:o + n], self.exp_avg_sq[o:o + n], lr, b1, b2, eps, wd,
                       self.step_count, gscale)
