@@ -173,7 +173,7 @@ def _load_ref_model_builder():
 
 
 def checkpoint_case():
-    seed, B, img, patch, D, H, Fd, blocks = 700, 2, 32, 8, 64, 2, 128, 2
+    seed, B, img, patch, D, H, Fd, blocks = 700, 2, 32, 8, 64, 1, 128, 2
     torch.manual_seed(seed)
     model = SimMIMViT(num_blocks=blocks, input_shape=(3, img, img), embed_dim=D, patch_size=patch, num_heads=H,
                       mlp_dim=Fd, dropout=0.0, mask_ratio=0.6)

@@ -38,6 +38,8 @@ def main():
         shapes = [(768, 768), (3072, 768), (768, 3072)]
         if os.environ.get("EXTRA"):
             shapes = [(2304, 768), (768, 2304)]
+        if os.environ.get("SHAPES"):            # "N,K;N,K"
+            shapes = [tuple(int(v) for v in sk.split(",")) for sk in os.environ["SHAPES"].split(";")]
         for (N, K) in shapes:
             A, B = rb(M, K), rb(N, K)
             bias = torch.randn(N, device=DEV)

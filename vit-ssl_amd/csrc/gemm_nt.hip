@@ -34,6 +34,21 @@
 #include <type_traits>
 #include "common.h"
 
+// cache policy of the epilogue stores (buffer aux bits: 1 = sc0, 2 = nt, 16 = sc1); developer experiments only
+#ifndef NT_STORE_AUX
+#define NT_STORE_AUX 0
+#endif
+// 1: every epilogue load / store instruction touches 8 rows x 128 bytes (whole cache lines; lanes
+// r and r^8 of a 16-lane row exchange halves with a DPP rotate) instead of 16 rows x 64 bytes
+#ifndef NT_ROWS128
+#define NT_ROWS128 0
+#endif
+// diagnostic builds only (tools/build_variant.sh): 1 = epilogue arithmetic and loads but NO stores,
+// 2 = stores but no GELU / dropout arithmetic and no residual / g' loads
+#ifndef NT_ABLATE
+#define NT_ABLATE 0
+#endif
+
 namespace {
 
 template <int V>
@@ -76,6 +91,10 @@ struct NtParams {
   int tiles_m, tiles_n;
   int group_n;   // tile columns per raster group (their B panels stay L2-resident)
   int k_chunk;   // split-K: K elements per blockIdx.y slice (0 = no split)
+  int stagger;   // ping-pong kernel: estimated time of one output tile in 100 MHz ticks (0 = no start-up stagger)
+#ifdef VITSSL_NT_STAMPS
+  unsigned long long* stamps;   // diagnostic build only (tools/nt_stamps.py): [wg][2 wave groups][16 rounds][4] x 100 MHz ticks
+#endif
 };
 
 // internal epilogue: fp32 output accumulated with atomics by the split-K slices (out0 is
@@ -116,6 +135,327 @@ __device__ __forceinline__ void wait_vmcnt() {
   if constexpr (N >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   else if constexpr (N >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// Fused epilogue of one 128x64 wave tile (shared by both main-loop variants).
+template <int EPI, typename CFG>
+__device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][CFG::MI], const long long m0, const int n0,
+                                            const int wm, const int wn, const int lane) {
+  constexpr int MI = CFG::MI;
+  // ------------------------------------------------------------------ epilogue
+  // All global traffic of the epilogue goes through raw buffer instructions on a window
+  // that starts at the tile's first row: rows past M fall outside num_records and columns
+  // past N get the out-of-range offset, so loads return 0 and stores are dropped WITHOUT a
+  // branch.  That lets every residual / g' load of a 64-column half be issued back to back
+  // before the first use (the branchy form waited for each 16-byte load in turn: 32
+  // dependent HBM round trips per wave, measured +65 us on the N = K = 768 projection).
+  float csum[4][4];
+  if (p.colsum) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) csum[j][r] = 0.f;
+  }
+  const int g4 = lane >> 4;                       // lane group = 16-lane row of the wave
+  // bf16 images: tile columns (j, j+1) exchange halves between lane rows (g, g^1) with
+  // v_permlane16_swap so that every lane moves 16 contiguous bytes (8 columns).
+  const bool wide = (p.N & 7) == 0;
+  constexpr unsigned OOB = 0x80000000u;
+  const long long rows_left = p.M - m0;
+  auto window = [&](const void* base, int elt) {
+    const unsigned long long bytes = (unsigned long long)rows_left * (unsigned long long)p.N * (unsigned)elt;
+    const unsigned rec = bytes > 0x80000000ull ? 0x80000000u : (unsigned)bytes;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)base + m0 * p.N * elt), 0, (int)rec, 0x00020000);
+  };
+  const unsigned row_l = (unsigned)(wm * CFG::WROWS + (lane & 15));      // + 16 i : row inside the tile
+  const unsigned un = (unsigned)p.N;
+  const int odd = g4 & 1;
+
+  // byte offset of this lane's 16-byte piece of the bf16 image (wide form), row i, pair jp
+  auto off_bf16_wide = [&](int i, int jp) -> unsigned {
+    const int n = n0 + wn * 64 + (2 * jp + odd) * 16 + 4 * (g4 - odd);
+    return n < p.N ? ((row_l + 16u * i) * un + (unsigned)n) * 2u : OOB;
+  };
+  auto off_elem = [&](int i, int n, unsigned elt) -> unsigned {
+    return n < p.N ? ((row_l + 16u * i) * un + (unsigned)n) * elt : OOB;
+  };
+  // ---- whole-line access shape: the two 64-byte halves (a, b) of a row's 128-byte line live in
+  // the same lane; lanes 0-7 of each 16-lane row keep rows r and take row r's... see line128_*
+  const unsigned row7 = (unsigned)(wm * CFG::WROWS + (lane & 7));        // + 16 i + 8 half
+  const int hsel = (lane >> 3) & 1;                                      // which 64-byte half this lane addresses
+  auto off_bf16_line = [&](int i, int half) -> unsigned {                // bf16 image, pair = hsel
+    const int n = n0 + wn * 64 + (2 * hsel + odd) * 16 + 4 * (g4 - odd);
+    return n < p.N ? ((row7 + 16u * i + 8u * half) * un + (unsigned)n) * 2u : OOB;
+  };
+  auto off_f32_line = [&](int i, int jp, int half) -> unsigned {         // fp32 image, tile h = hsel of pair jp
+    const int n = n0 + wn * 64 + (2 * jp + hsel) * 16 + 4 * g4;
+    return n < p.N ? ((row7 + 16u * i + 8u * half) * un + (unsigned)n) * 4u : OOB;
+  };
+  // (a, b) = the lane's two halves of row r.  to_lines: s1 = rows 0-7 (lanes 0-7 keep a, lanes 8-15
+  // receive b of lane r-8), s2 = rows 8-15 (lanes 0-7 receive a of lane r+8, lanes 8-15 keep b).
+  // from_lines is the inverse.  row_ror:8 = 0x128; bank mask 0xC = lanes 8-15, 0x3 = lanes 0-7.
+  auto to_lines = [&](const u32x4& a, const u32x4& b, u32x4& s1, u32x4& s2) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      s1[d] = (unsigned)__builtin_amdgcn_update_dpp((int)a[d], (int)b[d], 0x128, 0xF, 0xC, false);
+      s2[d] = (unsigned)__builtin_amdgcn_update_dpp((int)b[d], (int)a[d], 0x128, 0xF, 0x3, false);
+    }
+  };
+  auto from_lines = [&](const u32x4& l1, const u32x4& l2, u32x4& a, u32x4& b) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      a[d] = (unsigned)__builtin_amdgcn_update_dpp((int)l1[d], (int)l2[d], 0x128, 0xF, 0xC, false);
+      b[d] = (unsigned)__builtin_amdgcn_update_dpp((int)l2[d], (int)l1[d], 0x128, 0xF, 0x3, false);
+    }
+  };
+  auto pack_pair = [&](const u32x2& w0, const u32x2& w1) -> u32x4 {
+    // after the swap: even lane rows hold tile 2jp cols 4g .. 4g+7, odd rows tile 2jp+1 cols 4(g-1) .. 4(g-1)+7
+    auto lo = __builtin_amdgcn_permlane16_swap(w0[0], w1[0], false, false);
+    auto hi = __builtin_amdgcn_permlane16_swap(w0[1], w1[1], false, false);
+    return u32x4{lo[0], hi[0], lo[1], hi[1]};
+  };
+  // one row tile of a bf16 image: w[jp][h]
+  auto store_bf16_row = [&](__amdgpu_buffer_rsrc_t rs, int i, const u32x2 (&w)[2][2]) {
+    if (NT_ABLATE == 1) {
+      asm volatile("" ::"v"(w[0][0]), "v"(w[0][1]), "v"(w[1][0]), "v"(w[1][1]));
+      return;
+    }
+    if (wide) {
+      const u32x4 a = pack_pair(w[0][0], w[0][1]), b = pack_pair(w[1][0], w[1][1]);
+      if (NT_ROWS128) {
+        u32x4 s1, s2;
+        to_lines(a, b, s1, s2);
+        __builtin_amdgcn_raw_buffer_store_b128(s1, rs, off_bf16_line(i, 0), 0, NT_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(s2, rs, off_bf16_line(i, 1), 0, NT_STORE_AUX);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b128(a, rs, off_bf16_wide(i, 0), 0, NT_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(b, rs, off_bf16_wide(i, 1), 0, NT_STORE_AUX);
+      }
+    } else {
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        const int na = n0 + wn * 64 + (2 * jp) * 16 + 4 * g4;
+        __builtin_amdgcn_raw_buffer_store_b64(w[jp][0], rs, off_elem(i, na, 2u), 0, NT_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b64(w[jp][1], rs, off_elem(i, na + 16, 2u), 0, NT_STORE_AUX);
+      }
+    }
+  };
+  // one pair (32 columns) of a row tile of an fp32 image
+  auto store_f32_pair = [&](__amdgpu_buffer_rsrc_t rs, int i, int jp, const f32x4& v0, const f32x4& v1, const int (&nnp)[2]) {
+    if (NT_ABLATE == 1) {
+      asm volatile("" ::"v"(v0), "v"(v1));
+      return;
+    }
+    if (NT_ROWS128) {
+      u32x4 s1, s2;
+      to_lines(__builtin_bit_cast(u32x4, v0), __builtin_bit_cast(u32x4, v1), s1, s2);
+      __builtin_amdgcn_raw_buffer_store_b128(s1, rs, off_f32_line(i, jp, 0), 0, NT_STORE_AUX);
+      __builtin_amdgcn_raw_buffer_store_b128(s2, rs, off_f32_line(i, jp, 1), 0, NT_STORE_AUX);
+    } else {
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), rs, off_elem(i, nnp[0], 4u), 0, NT_STORE_AUX);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), rs, off_elem(i, nnp[1], 4u), 0, NT_STORE_AUX);
+    }
+  };
+  __amdgpu_buffer_rsrc_t rsOut0, rsOut1, rsAux;
+  if constexpr (EPI == VITSSL_EPI_BF16 || EPI == VITSSL_EPI_GELU || EPI == VITSSL_EPI_DGELU) rsOut0 = window(p.out0, 2);
+  if constexpr (EPI == VITSSL_EPI_F32 || EPI == VITSSL_EPI_RESID) rsOut0 = window(p.out0, 4);
+  if constexpr (EPI == VITSSL_EPI_GELU) rsOut1 = window(p.out1, 2);
+  if constexpr (EPI == VITSSL_EPI_RESID) rsAux = window(p.aux, 4);
+  if constexpr (EPI == VITSSL_EPI_DGELU) rsAux = window(p.aux, 2);
+
+  // Column bookkeeping of this wave's 64 columns: pair jp covers tiles (2jp, 2jp+1), half h
+  // of a pair is one 16-column tile; a lane owns 4 consecutive columns of each.
+  int nn[2][2];
+  bool okn[2][2];
+  f32x4 bias4[2][2];
+#pragma unroll
+  for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      nn[jp][h] = n0 + wn * 64 + (2 * jp + h) * 16 + 4 * g4;
+      okn[jp][h] = nn[jp][h] < p.N;
+      bias4[jp][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.bias && (EPI != EPI_F32_SPLITK || blockIdx.y == 0) && okn[jp][h]) bias4[jp][h] = *(const f32x4*)(p.bias + nn[jp][h]);
+    }
+
+  // Rows are walked in groups; inside a group the loop order is row -> pair, so the two
+  // 64-byte halves of every 128-byte output line are stored by consecutive instructions
+  // (pair-major order left them half an epilogue apart and the second bf16 image of the GELU
+  // epilogue was written at ~3 TB/s).  The residual / g' operands of a whole group are
+  // loaded before its first use.
+  constexpr int RG = MI % 2 != 0 ? 1 : ((EPI == VITSSL_EPI_RESID || MI % 4 != 0) ? 2 : 4);
+  static_assert(MI % RG == 0, "row groups must tile the wave's rows");
+#pragma unroll
+  for (int ig = 0; ig < MI; ig += RG) {
+    f32x4 res[RG][2][2];     // RESID: residual stream
+    u32x2 gpre[RG][2][2];    // DGELU: g' in accumulator layout
+    if constexpr (EPI == VITSSL_EPI_RESID) {
+#pragma unroll
+      for (int ii = 0; ii < RG; ++ii)
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+          if (NT_ABLATE == 2) {
+            res[ii][jp][0] = res[ii][jp][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+          } else if (NT_ROWS128) {
+            const u32x4 l1 = __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_f32_line(ig + ii, jp, 0), 0, 0);
+            const u32x4 l2 = __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_f32_line(ig + ii, jp, 1), 0, 0);
+            u32x4 a, b;
+            from_lines(l1, l2, a, b);
+            res[ii][jp][0] = __builtin_bit_cast(f32x4, a);
+            res[ii][jp][1] = __builtin_bit_cast(f32x4, b);
+          } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+              res[ii][jp][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_elem(ig + ii, nn[jp][h], 4u), 0, 0));
+          }
+        }
+    }
+    if constexpr (EPI == VITSSL_EPI_DGELU) {
+      if (wide) {
+        u32x4 raw[RG][2];
+#pragma unroll
+        for (int ii = 0; ii < RG; ++ii) {
+          if (NT_ROWS128) {
+            const u32x4 l1 = __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_bf16_line(ig + ii, 0), 0, 0);
+            const u32x4 l2 = __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_bf16_line(ig + ii, 1), 0, 0);
+            from_lines(l1, l2, raw[ii][0], raw[ii][1]);
+          } else {
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) raw[ii][jp] = __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_bf16_wide(ig + ii, jp), 0, 0);
+          }
+        }
+#pragma unroll
+        for (int ii = 0; ii < RG; ++ii)
+#pragma unroll
+          for (int jp = 0; jp < 2; ++jp) {
+            // inverse of the store shuffle (the swap is an involution)
+            auto sa = __builtin_amdgcn_permlane16_swap(raw[ii][jp][0], raw[ii][jp][2], false, false);
+            auto sb = __builtin_amdgcn_permlane16_swap(raw[ii][jp][1], raw[ii][jp][3], false, false);
+            gpre[ii][jp][0] = u32x2{sa[0], sb[0]};
+            gpre[ii][jp][1] = u32x2{sa[1], sb[1]};
+          }
+      } else {
+#pragma unroll
+        for (int ii = 0; ii < RG; ++ii)
+#pragma unroll
+          for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) gpre[ii][jp][h] = __builtin_amdgcn_raw_buffer_load_b64(rsAux, off_elem(ig + ii, nn[jp][h], 2u), 0, 0);
+      }
+    }
+
+#pragma unroll
+    for (int ii = 0; ii < RG; ++ii) {
+      const int i = ig + ii;
+      const long long m = m0 + wm * CFG::WROWS + i * 16 + (lane & 15);
+      const bool okm = m < p.M;
+      u32x2 out_a[2][2], out_b[2][2];   // bf16 images of this row, both pairs: stored together below
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        f32x4 v[2] = {acc[2 * jp][i] + bias4[jp][0], acc[2 * jp + 1][i] + bias4[jp][1]};
+
+        if constexpr (EPI == VITSSL_EPI_BF16) {
+          out_a[jp][0] = u32x2{pack_bf2(v[0][0], v[0][1]), pack_bf2(v[0][2], v[0][3])};
+          out_a[jp][1] = u32x2{pack_bf2(v[1][0], v[1][1]), pack_bf2(v[1][2], v[1][3])};
+        } else if constexpr (EPI == VITSSL_EPI_GELU) {
+          // u = bf16(acc + bias) (never stored); out1 = a = keep*scale*gelu(u) feeds the next
+          // GEMM; out0 = g' = keep*scale*gelu'(u) is what the backward dGELU epilogue needs.
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            float mult[4] = {1.f, 1.f, 1.f, 1.f};
+            if (p.drop_on && NT_ABLATE != 2) drop_mult4(p.dk, (unsigned long long)(m * p.N + nn[jp][h]) >> 2, mult);
+            float y[4], d[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if (NT_ABLATE == 2) {
+                y[r] = v[h][r];
+                d[r] = v[h][r] * 0.5f;
+                continue;
+              }
+              gelu_both(round_bf(v[h][r]), y[r], d[r]);
+              y[r] *= mult[r];
+              d[r] *= mult[r];
+            }
+            out_b[jp][h] = u32x2{pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
+            out_a[jp][h] = u32x2{pack_bf2(d[0], d[1]), pack_bf2(d[2], d[3])};
+          }
+        } else if constexpr (EPI == VITSSL_EPI_DGELU) {
+          // du = acc * g'  (g' already carries the dropout mask and its scale)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const u32x2 gpv = gpre[ii][jp][h];
+            v[h][0] *= bf_lo(gpv[0]);
+            v[h][1] *= bf_hi(gpv[0]);
+            v[h][2] *= bf_lo(gpv[1]);
+            v[h][3] *= bf_hi(gpv[1]);
+            out_a[jp][h] = u32x2{pack_bf2(v[h][0], v[h][1]), pack_bf2(v[h][2], v[h][3])};
+          }
+        } else if constexpr (EPI == EPI_F32_SPLITK) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            if (!(okm && okn[jp][h])) continue;
+            float* o = (float*)p.out0 + m * p.N + nn[jp][h];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) unsafeAtomicAdd(o + r, v[h][r]);
+          }
+        } else if constexpr (EPI == VITSSL_EPI_F32) {
+          store_f32_pair(rsOut0, i, jp, v[0], v[1], nn[jp]);
+        } else if constexpr (EPI == VITSSL_EPI_RESID) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            if (p.drop_on && NT_ABLATE != 2) {
+              float mult[4];
+              drop_mult4(p.dk, (unsigned long long)(m * p.N + nn[jp][h]) >> 2, mult);
+              v[h][0] *= mult[0]; v[h][1] *= mult[1]; v[h][2] *= mult[2]; v[h][3] *= mult[3];
+            }
+            v[h] += res[ii][jp][h];
+          }
+          store_f32_pair(rsOut0, i, jp, v[0], v[1], nn[jp]);
+        } else {   // VITSSL_EPI_EMBED (one launch per step: plain addressing)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            if (!(okm && okn[jp][h])) continue;
+            const long long img = m / p.embed.tokens;
+            const int rin = (int)(m - img * p.embed.tokens);
+            if (p.embed.mask && p.embed.mask[m]) v[h] = *(const f32x4*)(p.embed.mask_token + nn[jp][h]);
+            v[h] += *(const f32x4*)(p.embed.pos + (long long)(p.embed.tok_offset + rin) * p.N + nn[jp][h]);
+            const long long orow = img * p.embed.out_tokens + p.embed.tok_offset + rin;
+            *(f32x4*)((float*)p.out0 + orow * p.N + nn[jp][h]) = v[h];
+          }
+        }
+        if (p.colsum) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            if (okm && okn[jp][h]) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) csum[2 * jp + h][r] += v[h][r];
+            }
+        }
+      }
+      // the row's 128 bytes of every bf16 image leave in back-to-back instructions
+      if constexpr (EPI == VITSSL_EPI_BF16 || EPI == VITSSL_EPI_GELU || EPI == VITSSL_EPI_DGELU) {
+        store_bf16_row(rsOut0, i, out_a);
+      }
+      if constexpr (EPI == VITSSL_EPI_GELU) store_bf16_row(rsOut1, i, out_b);
+    }
+  }
+
+  if (p.colsum) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s = csum[j][r];
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        s += __shfl_xor(s, 8, 64);
+        const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4) + r;
+        if ((lane & 15) == 0 && n < p.N) atomicAdd(p.colsum + n, s);
+      }
+    }
+  }
+
 }
 
 template <int EPI, typename CFG>
@@ -255,238 +595,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
       }
     }
 
-    // ------------------------------------------------------------------ epilogue
-    // All global traffic of the epilogue goes through raw buffer instructions on a window
-    // that starts at the tile's first row: rows past M fall outside num_records and columns
-    // past N get the out-of-range offset, so loads return 0 and stores are dropped WITHOUT a
-    // branch.  That lets every residual / g' load of a 64-column half be issued back to back
-    // before the first use (the branchy form waited for each 16-byte load in turn: 32
-    // dependent HBM round trips per wave, measured +65 us on the N = K = 768 projection).
-    float csum[4][4];
-    if (p.colsum) {
-  #pragma unroll
-      for (int j = 0; j < 4; ++j)
-  #pragma unroll
-        for (int r = 0; r < 4; ++r) csum[j][r] = 0.f;
-    }
-    const int g4 = lane >> 4;                       // lane group = 16-lane row of the wave
-    // bf16 images: tile columns (j, j+1) exchange halves between lane rows (g, g^1) with
-    // v_permlane16_swap so that every lane moves 16 contiguous bytes (8 columns).
-    const bool wide = (p.N & 7) == 0;
-    constexpr unsigned OOB = 0x80000000u;
-    const long long rows_left = p.M - m0;
-    auto window = [&](const void* base, int elt) {
-      const unsigned long long bytes = (unsigned long long)rows_left * (unsigned long long)p.N * (unsigned)elt;
-      const unsigned rec = bytes > 0x80000000ull ? 0x80000000u : (unsigned)bytes;
-      return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)base + m0 * p.N * elt), 0, (int)rec, 0x00020000);
-    };
-    const unsigned row_l = (unsigned)(wm * CFG::WROWS + (lane & 15));      // + 16 i : row inside the tile
-    const unsigned un = (unsigned)p.N;
-    const int odd = g4 & 1;
-
-    // byte offset of this lane's 16-byte piece of the bf16 image (wide form), row i, pair jp
-    auto off_bf16_wide = [&](int i, int jp) -> unsigned {
-      const int n = n0 + wn * 64 + (2 * jp + odd) * 16 + 4 * (g4 - odd);
-      return n < p.N ? ((row_l + 16u * i) * un + (unsigned)n) * 2u : OOB;
-    };
-    auto off_elem = [&](int i, int n, unsigned elt) -> unsigned {
-      return n < p.N ? ((row_l + 16u * i) * un + (unsigned)n) * elt : OOB;
-    };
-    auto store_bf16_pair = [&](__amdgpu_buffer_rsrc_t rs, int i, int jp, const u32x2& w0, const u32x2& w1) {
-      if (wide) {
-        // after the swap: even rows hold tile 2jp  cols 4g .. 4g+7, odd rows tile 2jp+1 cols 4(g-1) .. 4(g-1)+7
-        auto lo = __builtin_amdgcn_permlane16_swap(w0[0], w1[0], false, false);
-        auto hi = __builtin_amdgcn_permlane16_swap(w0[1], w1[1], false, false);
-        const u32x4 v = {lo[0], hi[0], lo[1], hi[1]};
-        __builtin_amdgcn_raw_buffer_store_b128(v, rs, off_bf16_wide(i, jp), 0, 0);
-      } else {
-        const int na = n0 + wn * 64 + (2 * jp) * 16 + 4 * g4;
-        __builtin_amdgcn_raw_buffer_store_b64(w0, rs, off_elem(i, na, 2u), 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(w1, rs, off_elem(i, na + 16, 2u), 0, 0);
-      }
-    };
-
-    __amdgpu_buffer_rsrc_t rsOut0, rsOut1, rsAux;
-    if constexpr (EPI == VITSSL_EPI_BF16 || EPI == VITSSL_EPI_GELU || EPI == VITSSL_EPI_DGELU) rsOut0 = window(p.out0, 2);
-    if constexpr (EPI == VITSSL_EPI_F32 || EPI == VITSSL_EPI_RESID) rsOut0 = window(p.out0, 4);
-    if constexpr (EPI == VITSSL_EPI_GELU) rsOut1 = window(p.out1, 2);
-    if constexpr (EPI == VITSSL_EPI_RESID) rsAux = window(p.aux, 4);
-    if constexpr (EPI == VITSSL_EPI_DGELU) rsAux = window(p.aux, 2);
-
-    // Column bookkeeping of this wave's 64 columns: pair jp covers tiles (2jp, 2jp+1), half h
-    // of a pair is one 16-column tile; a lane owns 4 consecutive columns of each.
-    int nn[2][2];
-    bool okn[2][2];
-    f32x4 bias4[2][2];
-  #pragma unroll
-    for (int jp = 0; jp < 2; ++jp)
-  #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        nn[jp][h] = n0 + wn * 64 + (2 * jp + h) * 16 + 4 * g4;
-        okn[jp][h] = nn[jp][h] < p.N;
-        bias4[jp][h] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p.bias && (EPI != EPI_F32_SPLITK || blockIdx.y == 0) && okn[jp][h]) bias4[jp][h] = *(const f32x4*)(p.bias + nn[jp][h]);
-      }
-
-    // Rows are walked in groups; inside a group the loop order is row -> pair, so the two
-    // 64-byte halves of every 128-byte output line are stored by consecutive instructions
-    // (pair-major order left them half an epilogue apart and the second bf16 image of the GELU
-    // epilogue was written at ~3 TB/s).  The residual / g' operands of a whole group are
-    // loaded before its first use.
-    constexpr int RG = MI % 2 != 0 ? 1 : ((EPI == VITSSL_EPI_RESID || MI % 4 != 0) ? 2 : 4);
-    static_assert(MI % RG == 0, "row groups must tile the wave's rows");
-  #pragma unroll
-    for (int ig = 0; ig < MI; ig += RG) {
-      f32x4 res[RG][2][2];     // RESID: residual stream
-      u32x2 gpre[RG][2][2];    // DGELU: g' in accumulator layout
-      if constexpr (EPI == VITSSL_EPI_RESID) {
-  #pragma unroll
-        for (int ii = 0; ii < RG; ++ii)
-  #pragma unroll
-          for (int jp = 0; jp < 2; ++jp)
-  #pragma unroll
-            for (int h = 0; h < 2; ++h)
-              res[ii][jp][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_elem(ig + ii, nn[jp][h], 4u), 0, 0));
-      }
-      if constexpr (EPI == VITSSL_EPI_DGELU) {
-        if (wide) {
-          u32x4 raw[RG][2];
-  #pragma unroll
-          for (int ii = 0; ii < RG; ++ii)
-  #pragma unroll
-            for (int jp = 0; jp < 2; ++jp) raw[ii][jp] = __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_bf16_wide(ig + ii, jp), 0, 0);
-  #pragma unroll
-          for (int ii = 0; ii < RG; ++ii)
-  #pragma unroll
-            for (int jp = 0; jp < 2; ++jp) {
-              // inverse of the store shuffle (the swap is an involution)
-              auto sa = __builtin_amdgcn_permlane16_swap(raw[ii][jp][0], raw[ii][jp][2], false, false);
-              auto sb = __builtin_amdgcn_permlane16_swap(raw[ii][jp][1], raw[ii][jp][3], false, false);
-              gpre[ii][jp][0] = u32x2{sa[0], sb[0]};
-              gpre[ii][jp][1] = u32x2{sa[1], sb[1]};
-            }
-        } else {
-  #pragma unroll
-          for (int ii = 0; ii < RG; ++ii)
-  #pragma unroll
-            for (int jp = 0; jp < 2; ++jp)
-  #pragma unroll
-              for (int h = 0; h < 2; ++h) gpre[ii][jp][h] = __builtin_amdgcn_raw_buffer_load_b64(rsAux, off_elem(ig + ii, nn[jp][h], 2u), 0, 0);
-        }
-      }
-
-  #pragma unroll
-      for (int ii = 0; ii < RG; ++ii) {
-        const int i = ig + ii;
-        const long long m = m0 + wm * CFG::WROWS + i * 16 + (lane & 15);
-        const bool okm = m < p.M;
-        u32x2 out_a[2][2], out_b[2][2];   // bf16 images of this row, both pairs: stored together below
-  #pragma unroll
-        for (int jp = 0; jp < 2; ++jp) {
-          f32x4 v[2] = {acc[2 * jp][i] + bias4[jp][0], acc[2 * jp + 1][i] + bias4[jp][1]};
-
-          if constexpr (EPI == VITSSL_EPI_BF16) {
-            out_a[jp][0] = u32x2{pack_bf2(v[0][0], v[0][1]), pack_bf2(v[0][2], v[0][3])};
-            out_a[jp][1] = u32x2{pack_bf2(v[1][0], v[1][1]), pack_bf2(v[1][2], v[1][3])};
-          } else if constexpr (EPI == VITSSL_EPI_GELU) {
-            // u = bf16(acc + bias) (never stored); out1 = a = keep*scale*gelu(u) feeds the next
-            // GEMM; out0 = g' = keep*scale*gelu'(u) is what the backward dGELU epilogue needs.
-  #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              float mult[4] = {1.f, 1.f, 1.f, 1.f};
-              if (p.drop_on) drop_mult4(p.dk, (unsigned long long)(m * p.N + nn[jp][h]) >> 2, mult);
-              float y[4], d[4];
-  #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                gelu_both(round_bf(v[h][r]), y[r], d[r]);
-                y[r] *= mult[r];
-                d[r] *= mult[r];
-              }
-              out_b[jp][h] = u32x2{pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
-              out_a[jp][h] = u32x2{pack_bf2(d[0], d[1]), pack_bf2(d[2], d[3])};
-            }
-          } else if constexpr (EPI == VITSSL_EPI_DGELU) {
-            // du = acc * g'  (g' already carries the dropout mask and its scale)
-  #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              const u32x2 gpv = gpre[ii][jp][h];
-              v[h][0] *= bf_lo(gpv[0]);
-              v[h][1] *= bf_hi(gpv[0]);
-              v[h][2] *= bf_lo(gpv[1]);
-              v[h][3] *= bf_hi(gpv[1]);
-              out_a[jp][h] = u32x2{pack_bf2(v[h][0], v[h][1]), pack_bf2(v[h][2], v[h][3])};
-            }
-          } else if constexpr (EPI == EPI_F32_SPLITK) {
-  #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              if (!(okm && okn[jp][h])) continue;
-              float* o = (float*)p.out0 + m * p.N + nn[jp][h];
-  #pragma unroll
-              for (int r = 0; r < 4; ++r) unsafeAtomicAdd(o + r, v[h][r]);
-            }
-          } else if constexpr (EPI == VITSSL_EPI_F32) {
-  #pragma unroll
-            for (int h = 0; h < 2; ++h)
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[h]), rsOut0, off_elem(i, nn[jp][h], 4u), 0, 0);
-          } else if constexpr (EPI == VITSSL_EPI_RESID) {
-  #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              if (p.drop_on) {
-                float mult[4];
-                drop_mult4(p.dk, (unsigned long long)(m * p.N + nn[jp][h]) >> 2, mult);
-                v[h][0] *= mult[0]; v[h][1] *= mult[1]; v[h][2] *= mult[2]; v[h][3] *= mult[3];
-              }
-              v[h] += res[ii][jp][h];
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[h]), rsOut0, off_elem(i, nn[jp][h], 4u), 0, 0);
-            }
-          } else {   // VITSSL_EPI_EMBED (one launch per step: plain addressing)
-  #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              if (!(okm && okn[jp][h])) continue;
-              const long long img = m / p.embed.tokens;
-              const int rin = (int)(m - img * p.embed.tokens);
-              if (p.embed.mask && p.embed.mask[m]) v[h] = *(const f32x4*)(p.embed.mask_token + nn[jp][h]);
-              v[h] += *(const f32x4*)(p.embed.pos + (long long)(p.embed.tok_offset + rin) * p.N + nn[jp][h]);
-              const long long orow = img * p.embed.out_tokens + p.embed.tok_offset + rin;
-              *(f32x4*)((float*)p.out0 + orow * p.N + nn[jp][h]) = v[h];
-            }
-          }
-          if (p.colsum) {
-  #pragma unroll
-            for (int h = 0; h < 2; ++h)
-              if (okm && okn[jp][h]) {
-  #pragma unroll
-                for (int r = 0; r < 4; ++r) csum[2 * jp + h][r] += v[h][r];
-              }
-          }
-        }
-        // the row's 128 bytes of every bf16 image leave in back-to-back instructions
-        if constexpr (EPI == VITSSL_EPI_BF16 || EPI == VITSSL_EPI_GELU || EPI == VITSSL_EPI_DGELU) {
-          store_bf16_pair(rsOut0, i, 0, out_a[0][0], out_a[0][1]);
-          store_bf16_pair(rsOut0, i, 1, out_a[1][0], out_a[1][1]);
-        }
-        if constexpr (EPI == VITSSL_EPI_GELU) {
-          store_bf16_pair(rsOut1, i, 0, out_b[0][0], out_b[0][1]);
-          store_bf16_pair(rsOut1, i, 1, out_b[1][0], out_b[1][1]);
-        }
-      }
-    }
-
-    if (p.colsum) {
-  #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-  #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float s = csum[j][r];
-          s += __shfl_xor(s, 1, 64);
-          s += __shfl_xor(s, 2, 64);
-          s += __shfl_xor(s, 4, 64);
-          s += __shfl_xor(s, 8, 64);
-          const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4) + r;
-          if ((lane & 15) == 0 && n < p.N) atomicAdd(p.colsum + n, s);
-        }
-      }
-    }
+    nt_epilogue<EPI, CFG>(p, acc, m0, n0, wm, wn, lane);
 
     if (!has_next) break;
     // The next tile's first stage was issued before every store above; vector-memory
@@ -500,6 +609,336 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
   }
 }
 
+// ====================================================================================
+// Ping-pong main loop (BK = 64 tiles, 8 waves): the K-step is cut into 4 phases of one
+// 64x32 accumulator quadrant each (16 MFMAs); every phase is {LOAD: fragment ds_reads + the
+// LDS-DMA of one half-tile "unit" ; s_barrier ; COMPUTE: 16 MFMAs ; s_barrier}.  Waves 4-7
+// (the second wave of every SIMD: tile rows 128..255) run ONE barrier behind waves 0-3, so on
+// each SIMD one wave is in its MFMA cluster while its partner reads LDS / issues DMA -- the
+// matrix pipe never waits for a fragment read and the two waves never contend for it.
+//
+// Staging never drains: operands are DMA'd in units of 128 tile rows x 64 k (16 KiB = 2
+// wave-instructions per wave): A0/A1 = m-half 0/1 of BOTH wave rows, B0/B1 = n-half 0/1 of all
+// four wave columns.  The unit issued in phase p of K-tile t is
+//     p0: B1(t+1)   p1: A1(t+1)   p2: B0(t+2)   p3: A0(t+2)
+// i.e. a region is refilled two phases after its last fragment read (B0/A0 are read in p0, B1 in
+// p1, A1 in p2) and every unit is issued 5-6 phases before its first read.  Waits are counted:
+// p0, p1 and p3 end their LOAD part with s_waitcnt vmcnt(8) = "everything but the 4 newest units
+// has landed", which is exactly what the NEXT phase reads; p2 needs no wait.  Rules this obeys
+// (MI355X guide, "Read a staged buffer one phase AFTER the wait that retires it"): the wait that
+// covers a unit sits before the first barrier of the phase preceding its first read (one extra
+// barrier because the two wave groups are staggered), and a region is re-issued no earlier
+// than two phases after its last read.
+//
+// The K-tile stream is continuous across OUTPUT tiles (persistent workgroups): while the last
+// K-tiles of one output tile are multiplied, the first units of the workgroup's next output tile
+// are already in flight, so there is no prologue bubble after the first tile; the epilogue runs
+// with ~80 KiB of the next tile staged.  The vector-memory operations of the epilogue sit in the
+// same in-order counter, so the first K-tile after an epilogue waits with vmcnt(8 + S), S = a
+// lower bound of the epilogue's operations per wave (a smaller count only waits longer).
+// Past the last tile the stream issues out-of-range DMA (zero fill, no memory traffic) so every
+// count stays uniform.
+template <int EPI, int MI>
+constexpr int nt_epi_vmem_ops() {
+  // unconditional buffer loads + stores per wave in nt_epilogue (wide form; the narrow form has more)
+  if (NT_ABLATE != 0) return 0;
+  return EPI == VITSSL_EPI_BF16 ? 2 * MI
+         : (EPI == VITSSL_EPI_GELU || EPI == VITSSL_EPI_DGELU || EPI == VITSSL_EPI_F32) ? 4 * MI
+         : EPI == VITSSL_EPI_RESID ? 8 * MI
+         : 0;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_exact() {
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// (target builtins with immediate operands are kept out of the kernel's lambdas: on the host pass a
+// lambda body is checked eagerly and the kernel would silently lose its stub)
+__device__ __forceinline__ void dma16_to_lds(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, unsigned voffset) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_wave_base), 16, voffset, 0, 0, 0);
+}
+
+template <int EPI, typename CFG>
+__global__ __launch_bounds__(CFG::THREADS, 2) void gemm_nt_pp_kernel(NtParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  static_assert(CFG::BK == 64 && CFG::WM == 2 && CFG::WN == 4, "ping-pong loop is written for 8 waves, BK = 64");
+  constexpr int BM = CFG::BM, BN = CFG::BN, MI = CFG::MI;
+  constexpr int MH1 = MI - 4;                          // 16-row tiles in the second m-half (first has 4)
+  constexpr int BUF = CFG::BUF_BYTES;
+  constexpr int DUMMY = 2 * BUF;                       // 1 KiB sink for the slots a short A1 unit does not need
+  constexpr unsigned OOBV = 0x80000000u;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int G = gridDim.x;
+  const int bid = blockIdx.x;
+
+  auto tile_of = [&](int r, long long& m0, int& n0) -> bool {      // same raster as gemm_nt_kernel
+    const int base = r * G;
+    const int cnt = min(G, ntiles - base);
+    if (bid >= cnt) return false;
+    const int xcd = bid & 7, q = cnt >> 3, rr = cnt & 7;
+    const int wgid = base + (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    const int full = p.tiles_m * p.group_n;
+    const int cg = wgid / full;
+    const int rem = wgid - cg * full;
+    const int gw = min(p.group_n, p.tiles_n - cg * p.group_n);
+    const int tile_m = rem / gw;
+    m0 = (long long)tile_m * BM;
+    n0 = (cg * p.group_n + (rem - tile_m * gw)) * BN;
+    return true;
+  };
+
+  long long m0 = 0;
+  int n0 = 0;
+  if (!tile_of(0, m0, n0)) return;                     // workgroup-uniform, before any barrier
+
+  // Start-up stagger.  Every workgroup runs the same program on equal tiles, so left alone the
+  // whole chip alternates between "all CUs in the K loop" (HBM nearly idle) and "all CUs in the
+  // epilogue" (a 32-128 MB burst at the HBM rate with the matrix pipes idle): measured 9-23 us of
+  // epilogue per tile for the two-image / residual epilogues against 2-4 us of issue time.  With
+  // the static tile assignment the workgroups b >= ntiles % G own one tile fewer than the others:
+  // they can start up to one tile time late for free.  Spreading their start over that window
+  // puts their epilogues beside other CUs' K loops.
+  if (p.stagger > 0) {
+    const int rem = ntiles % G;
+    if (rem != 0 && bid >= rem && wave == 0) {
+      const unsigned long long delay = (unsigned long long)p.stagger * (unsigned)(bid - rem) / (unsigned)(G - rem);
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      while (__builtin_amdgcn_s_memrealtime() - t0 < delay) __builtin_amdgcn_s_sleep(8);
+    }   // the other waves are held by the prologue's barrier
+  }
+
+  const unsigned long long a_bytes = (unsigned long long)p.M * p.K * 2ull;
+  const unsigned long long b_bytes = (unsigned long long)p.N * p.K * 2ull;
+  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)a_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)b_bytes, 0x00020000);
+  const int nk = p.K / 64;
+  const unsigned rowb = (unsigned)p.K * 2u;            // bytes per operand row
+
+  // ---- staging slots: every wave issues exactly 2 DMA instructions per unit (8 rows x 128 B each)
+  // unit A_h: rows g*WROWS + 64 h + 8 q (+ lane/8); unit B_h: rows 64 c + 32 h + 8 q
+  unsigned voffA[2][2], voffB[2][2];                   // tile-relative byte offsets of this lane's 16-byte chunk
+  int ldsA[2][2], ldsB[2][2];                          // wave-uniform LDS byte offsets inside a buffer
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int s = 2 * wave + e;
+      {
+        const int per_g = h == 0 ? 8 : 2 * MH1;        // slots per wave row in this unit
+        const bool ok = s < 2 * per_g;
+        const int g = s / per_g, q = s - g * per_g;
+        const int r = g * CFG::WROWS + 64 * h + 8 * q;
+        const int rl = r + (lane >> 3);
+        const int sc = (lane & 7) ^ ((rl >> 1) & 7);
+        voffA[h][e] = ok ? (unsigned)rl * rowb + (unsigned)sc * 16u : OOBV;
+        ldsA[h][e] = ok ? r * 128 : DUMMY;
+      }
+      {
+        const int c = s >> 2, q = s & 3;
+        const int r = 64 * c + 32 * h + 8 * q;
+        const int rl = r + (lane >> 3);
+        const int sc = (lane & 7) ^ ((rl >> 1) & 7);
+        voffB[h][e] = (unsigned)rl * rowb + (unsigned)sc * 16u;
+        ldsB[h][e] = CFG::A_BYTES + r * 128;
+      }
+    }
+
+  // ---- staging stream: K-tiles in the order they will be multiplied, across output tiles
+  struct Cur {
+    int round, kt;
+    unsigned a, b;          // byte offset of (tile row 0, k0) in A / B; OOBV once the stream has ended
+  };
+  auto cur_at = [&](int round) {
+    Cur c;
+    c.round = round;
+    c.kt = 0;
+    long long mm;
+    int nn;
+    if (tile_of(round, mm, nn)) {
+      c.a = (unsigned)((unsigned long long)mm * rowb);
+      c.b = (unsigned)((unsigned long long)nn * rowb);
+    } else {
+      c.a = c.b = OOBV;
+    }
+    return c;
+  };
+  auto cur_next = [&](const Cur& c) {
+    if (c.a == OOBV) return c;
+    if (c.kt + 1 < nk) {
+      Cur n = c;
+      n.kt += 1;
+      n.a += 128u;
+      n.b += 128u;
+      return n;
+    }
+    return cur_at(c.round + 1);
+  };
+  // DMA of one unit: 2 wave-instructions.  bufsel = LDS buffer (0/1) of the unit's K-tile.
+  auto stage_a = [&](const Cur& c, int bufsel, auto h_c) {
+    constexpr int h = decltype(h_c)::value;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const bool live = ldsA[h][e] != DUMMY;
+      // (an ended stream has c.a = OOBV: the sum is out of range for every live slot -> zero fill)
+      dma16_to_lds(rsA, smem + (live ? bufsel * BUF : 0) + ldsA[h][e], voffA[h][e] + c.a);
+    }
+  };
+  auto stage_b = [&](const Cur& c, int bufsel, auto h_c) {
+    constexpr int h = decltype(h_c)::value;
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+      dma16_to_lds(rsB, smem + bufsel * BUF + ldsB[h][e], voffB[h][e] + c.b);
+  };
+
+  // ---- fragment addressing (as in gemm_nt_kernel)
+  const int frag_row = lane & 15;
+  const int kq = lane >> 4;
+  const int swz = nt_swz<64>(frag_row);
+  const int offA0 = (wm * CFG::WROWS + frag_row) * 128 + (((0 + kq) ^ swz) << 4);
+  const int offA1 = (wm * CFG::WROWS + frag_row) * 128 + (((4 + kq) ^ swz) << 4);
+  const int offB0 = CFG::A_BYTES + (wn * 64 + frag_row) * 128 + (((0 + kq) ^ swz) << 4);
+  const int offB1 = CFG::A_BYTES + (wn * 64 + frag_row) * 128 + (((4 + kq) ^ swz) << 4);
+
+  f32x4 acc[4][MI];
+  bf16x8 fa[2][4];          // A fragments of the current m-half: [kk][tile]
+  bf16x8 fb[2][2][2];       // B fragments: [n-half][kk][tile]
+
+  auto read_a = [&](const char* buf, auto mh_c) {
+    constexpr int mh = decltype(mh_c)::value;
+    constexpr int cnt = mh == 0 ? 4 : MH1;
+#pragma unroll
+    for (int ii = 0; ii < cnt; ++ii) {
+      fa[0][ii] = *(const bf16x8*)(buf + offA0 + (4 * mh + ii) * 2048);
+      fa[1][ii] = *(const bf16x8*)(buf + offA1 + (4 * mh + ii) * 2048);
+    }
+  };
+  auto read_b = [&](const char* buf, auto nh_c) {
+    constexpr int nh = decltype(nh_c)::value;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      fb[nh][0][jj] = *(const bf16x8*)(buf + offB0 + (2 * nh + jj) * 2048);
+      fb[nh][1][jj] = *(const bf16x8*)(buf + offB1 + (2 * nh + jj) * 2048);
+    }
+  };
+  auto mma_quad = [&](auto mh_c, auto nh_c) {
+    constexpr int mh = decltype(mh_c)::value, nh = decltype(nh_c)::value;
+    constexpr int cnt = mh == 0 ? 4 : MH1;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int ii = 0; ii < cnt; ++ii)
+          acc[2 * nh + jj][4 * mh + ii] =
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nh][kk][jj], fa[kk][ii], acc[2 * nh + jj][4 * mh + ii], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto section = [&]() {                               // end of a LOAD or COMPUTE part
+    // the raw s_barrier carries no fence: the empty asm statements keep the optimiser from moving
+    // fragment loads across it, sched_barrier keeps the machine scheduler from moving MFMAs
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+  };
+
+  // One K-tile = 4 phases.  NW = counted wait of p0 / p1 / p3 (8, or 8 + S right after an epilogue).
+  auto ktile = [&](int buf, const Cur& c1, const Cur& c2, bool last_of_round, auto nw_c) {
+    constexpr int NW = decltype(nw_c)::value;
+    const char* cur = smem + buf * BUF;
+    // p0: quadrant (m0, n0)
+    read_b(cur, IC<0>{});
+    read_a(cur, IC<0>{});
+    stage_b(c1, buf ^ 1, IC<1>{});
+    wait_vmcnt_exact<NW>();
+    section();
+    mma_quad(IC<0>{}, IC<0>{});
+    section();
+    // p1: quadrant (m0, n1)
+    read_b(cur, IC<1>{});
+    stage_a(c1, buf ^ 1, IC<1>{});
+    wait_vmcnt_exact<NW>();
+    section();
+    mma_quad(IC<0>{}, IC<1>{});
+    section();
+    // p2: quadrant (m1, n1)
+    read_a(cur, IC<1>{});
+    stage_b(c2, buf, IC<0>{});
+    section();
+    mma_quad(IC<1>{}, IC<1>{});
+    section();
+    // p3: quadrant (m1, n0)
+    stage_a(c2, buf, IC<0>{});
+    wait_vmcnt_exact<NW>();
+    section();
+    mma_quad(IC<1>{}, IC<0>{});
+    // waves 4-7 leave the stagger at the end of an output tile (they re-enter it with the
+    // barrier at the top of the next one): both wave groups then run their epilogues together
+    if (!(last_of_round && wm == 1)) section();
+  };
+
+  // ---- prologue: K-tiles 0 and (B0, A0 of) 1 of the stream
+  Cur c0 = cur_at(0);
+  Cur c1 = cur_next(c0);
+  stage_b(c0, 0, IC<0>{});
+  stage_a(c0, 0, IC<0>{});
+  stage_b(c0, 0, IC<1>{});
+  stage_a(c0, 0, IC<1>{});
+  stage_b(c1, 1, IC<0>{});
+  stage_a(c1, 1, IC<0>{});
+  Cur c2 = cur_next(c1);
+  wait_vmcnt_exact<8>();                               // B0, A0 of K-tile 0 have landed
+  section();
+
+  constexpr int S = nt_epi_vmem_ops<EPI, MI>();
+  constexpr int NW_POST = (8 + S) > 63 ? 63 : (8 + S);
+  int buf = 0;
+#ifdef VITSSL_NT_STAMPS
+  auto stamp = [&](int round, int which) {
+    if (p.stamps && (wave & 3) == 0 && lane == 0 && round < 16)
+      p.stamps[(((size_t)bid * 2 + wm) * 16 + round) * 4 + which] = __builtin_amdgcn_s_memrealtime();
+  };
+#else
+  auto stamp = [&](int, int) {};
+#endif
+  for (int round = 0;; ++round) {
+    stamp(round, 0);
+    if (wm == 1) section();                            // waves 4-7 run one barrier behind waves 0-3
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < nk; ++t) {
+      const bool last = t + 1 == nk;
+      if (t == 0 && round > 0) ktile(buf, c1, c2, last, IC<NW_POST>{});
+      else ktile(buf, c1, c2, last, IC<8>{});
+      c1 = c2;
+      c2 = cur_next(c2);
+      buf ^= 1;
+    }
+    stamp(round, 1);
+    nt_epilogue<EPI, CFG>(p, acc, m0, n0, wm, wn, lane);
+    stamp(round, 2);
+#ifdef VITSSL_NT_STAMPS
+    if (p.stamps) {                                    // diagnostic: when have this wave's stores been acknowledged?
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stamp(round, 3);
+    }
+#endif
+    if (!tile_of(round + 1, m0, n0)) break;
+  }
+  // the stream's trailing (out-of-range, zero-filling) DMA must have retired before the LDS is released
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 int cu_count() {
   static int n = 0;
   if (!n) {
@@ -509,6 +948,46 @@ int cu_count() {
     if (n <= 0) n = 256;
   }
   return n;
+}
+
+// 1 (default): 8-wave BK = 64 tiles run the ping-pong kernel; 0: the two-phase loop (VITSSL_NT_PP, developer knob)
+int nt_pp_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("VITSSL_NT_PP");
+    v = e ? atoi(e) : 1;
+  }
+  return v;
+}
+
+template <int EPI, typename CFG>
+int launch_pp(NtParams p, hipStream_t s) {
+  constexpr int LDS = 2 * CFG::BUF_BYTES + 1024;
+  static bool attr_done = false;  // idempotent; a benign race sets the same value
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      vitssl_set_error("gemm_nt: cannot raise dynamic LDS to %d: %s", LDS, hipGetErrorString(e));
+      return VITSSL_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  const long long ntiles = (long long)p.tiles_m * p.tiles_n;
+  const long long slots = cu_count();
+  const long long grid = ntiles < slots ? ntiles : slots;
+  // tile-time estimate for the start-up stagger (us): K loop ~1.45 us per 256-row K-tile + an uncontended epilogue
+  static float stagger_scale = -1.f;
+  if (stagger_scale < 0.f) {
+    const char* e = getenv("VITSSL_NT_STAGGER");       // developer knob: scale of the window, 0 = off
+    stagger_scale = e ? (float)atof(e) : 1.0f;
+  }
+  const float epi_us = EPI == VITSSL_EPI_BF16 ? 2.f : EPI == VITSSL_EPI_GELU ? 7.f : EPI == VITSSL_EPI_DGELU ? 5.f
+                       : EPI == VITSSL_EPI_RESID ? 8.f : 4.f;
+  const float tile_us = (float)(p.K / 64) * 1.45f * (float)CFG::MI / 8.f + epi_us;
+  p.stagger = (int)(stagger_scale * tile_us * 100.f);
+  hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, CFG>), dim3((unsigned)grid), dim3(CFG::THREADS), LDS, s, p);
+  VS_CHECK_LAUNCH("gemm_nt_pp");
+  return VITSSL_OK;
 }
 
 template <int EPI, typename CFG>
@@ -532,6 +1011,9 @@ int launch_cfg(NtParams p, hipStream_t s) {
   else if (p.tiles_n % 4 == 0) p.group_n = 4;
   else if (p.tiles_n % 3 == 0) p.group_n = 3;
   else p.group_n = want < 4 ? want : 4;
+  if constexpr (CFG::WAVES == 8 && CFG::BK == 64 && EPI != EPI_F32_SPLITK) {
+    if (nt_pp_enabled() && p.k_chunk == 0) return launch_pp<EPI, CFG>(p, s);
+  }
   // Persistent workgroups.  Measured on MI355X (bench.py, same box, alternating runs): with
   // K = 768 / 3072 (ViT-B) the NT family takes 23.12 ms per step either way and the whole step
   // is 0.2-0.5 ms slower persistent; with K = 384 (ViT-S: 6 K-steps per tile, the fixed
@@ -627,6 +1109,11 @@ int launch_nt(const NtParams& p, hipStream_t s) {
 
 }  // namespace
 
+#ifdef VITSSL_NT_STAMPS
+static unsigned long long* g_nt_stamps = nullptr;
+extern "C" void vitssl_debug_nt_stamps(void* buf) { g_nt_stamps = (unsigned long long*)buf; }
+#endif
+
 extern "C" int vitssl_gemm_bf16_nt(const vitssl_gemm_t* g, void* stream) {
   VS_CHECK_ARG(g && g->A && g->B && g->out0, "gemm_nt: null operand");
   VS_CHECK_ARG(g->M > 0 && g->N > 0 && g->K > 0, "gemm_nt: empty problem M=%lld N=%d K=%d", (long long)g->M, g->N, g->K);
@@ -651,6 +1138,10 @@ extern "C" int vitssl_gemm_bf16_nt(const vitssl_gemm_t* g, void* stream) {
   p.embed = g->embed;
   p.tiles_m = p.tiles_n = p.group_n = 0;   // set per tile configuration in launch_cfg
   p.k_chunk = 0;
+  p.stagger = 0;
+#ifdef VITSSL_NT_STAMPS
+  p.stamps = g_nt_stamps;
+#endif
   hipStream_t s = (hipStream_t)stream;
   switch (g->epilogue) {
     case VITSSL_EPI_BF16: return launch_nt<VITSSL_EPI_BF16>(p, s);

@@ -6,7 +6,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvitssl_hip.so")
+LIB_PATH = os.environ.get("VITSSL_LIB") or os.path.join(_HERE, "libvitssl_hip.so")   # VITSSL_LIB: developer override (kernel A/B builds)
 HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "include", "vitssl_hip.h"))
 
 
