@@ -32,6 +32,19 @@ MODELS = {  # standard ViT families
     "vit_l": dict(D=1024, L=24, H=16, F=4096),
 }
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md
+PEAK_HBM_TBS = 8.0         # HBM3E spec (6.29 TB/s measured copy ceiling), MI355X_MICROARCH.md
+
+
+def cpu_quota():
+    """CPU cores this process may actually use: cgroup v2 quota (cpu.max), else the affinity mask."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            return max(1, int(float(q) / float(per) + 0.5)), f"cgroup cpu.max {q}/{per}"
+    except (OSError, ValueError):
+        pass
+    n = len(os.sched_getaffinity(0))
+    return n, "sched_getaffinity"
 
 
 def train_flops_per_image(D, L, H, F, N, Pd, nm):
@@ -77,7 +90,9 @@ def cpu_baseline(cfg, img, P, ratio, seconds_budget=25.0):
     from oracle import vit_oracle as O
     from vit_core.ssl.simmim import SimMIMViT
     torch.manual_seed(42)
-    cores = torch.get_num_threads()
+    cores, quota_src = cpu_quota()
+    cores = min(cores, os.cpu_count() or cores)
+    torch.set_num_threads(cores)                           # a pool larger than the quota only spins and gets throttled
     Bc = 8
     model = SimMIMViT(num_blocks=cfg["L"], input_shape=(3, img, img), embed_dim=cfg["D"], patch_size=P,
                       num_heads=cfg["H"], mlp_dim=cfg["F"], dropout=0.1, mask_ratio=ratio)
@@ -101,7 +116,8 @@ def cpu_baseline(cfg, img, P, ratio, seconds_budget=25.0):
             break
     times.sort()
     med = times[len(times) // 2]
-    return {"value": round(Bc / med, 3), "unit": "images/s", "cores": cores, "cpu": _cpu_model(), "kind": "port",
+    return {"value": round(Bc / med, 3), "unit": "images/s", "cores": cores, "cores_source": quota_src,
+            "host_logical_cpus": os.cpu_count(), "cpu": _cpu_model(), "kind": "port",
             "sample": f"same model/inputs shape, batch {Bc}, {len(times)} measured step(s) after 1 warm-up, fp32 eager, dropout 0.1, AdamW"}
 
 
@@ -142,6 +158,11 @@ def main():
     from vitssl_hip.optim import FusedAdamW
 
     cfg = MODELS[args.model]
+    # The CPU baseline runs FIRST (rank 0, N = 1): the GPU phase then ends the process, where the
+    # driver's utilisation sampler can see it.
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, args.img, args.patch, args.mask_ratio)
     # Host hygiene for the GPU phase: a GPU job gets a small CPU share; torch's default
     # (one OpenMP worker per core, spin-waiting after every parallel CPU op) exhausts it and
     # the whole process is throttled for tens of ms.  The CPU-baseline leg restores all cores.
@@ -152,10 +173,17 @@ def main():
                       num_heads=cfg["H"], mlp_dim=cfg["F"], dropout=args.dropout, mask_ratio=args.mask_ratio).to(dev).train()
     store = model.flat_store()
     reducer = None
+    dp = None
     if world > 1:
         dist.broadcast(store.flat, 0)
         store.mark_dirty()
         reducer = GradReducer(store.gflat)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                               # what the collective library itself sees
+        dp = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "allreduce_of_ones": float(ones),
+              "grad_bytes": 4 * store.gflat.numel(), "bucket_mb": reducer.bucket_elems * 4 / 2 ** 20}
+        if float(ones) != world:
+            raise SystemExit(f"all_reduce over {world} ranks returned {float(ones)}: the process group is not what torchrun launched")
     opt = FusedAdamW(store, lr=1e-4, weight_decay=1e-3)
     gen = torch.Generator().manual_seed(42 + rank)
     x = torch.rand(args.batch, 3, args.img, args.img, generator=gen).to(dev)
@@ -180,6 +208,31 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt)
     final_loss = float(loss)
+    # the fused loss of the last timed step equals mean|pred - target| recomputed by torch on its outputs
+    recomputed = float((model.last_pred - model.last_targets).abs().mean())
+    if not (final_loss == final_loss and abs(recomputed - final_loss) <= 1e-4 * max(1.0, abs(final_loss))):
+        raise SystemExit(f"bench sanity: fused loss {final_loss} vs recomputed {recomputed}")
+    if world > 1:
+        # exposed communication = step with the overlapped all-reduce - the same step without any reduction
+        # (diagnostic only, after the timed region; the un-reduced steps de-synchronise nothing: same data per rank)
+        nb, nbytes = reducer.stats()
+        k = max(3, min(10, args.steps))
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(k):
+            model.train_step(x, opt, reducer)
+        sync()
+        with_comm = (time.perf_counter() - t1) / k
+        t1 = time.perf_counter()
+        for _ in range(k):
+            model.train_step(x, opt, None)
+        sync()
+        without = (time.perf_counter() - t1) / k
+        dist.broadcast(store.flat, 0)                       # replicas drifted during the un-reduced steps
+        store.mark_dirty()
+        dp.update(buckets_per_step=nb, reduced_bytes_per_step=nbytes, ms_step_with_allreduce=round(with_comm * 1e3, 3),
+                  ms_step_without_allreduce=round(without * 1e3, 3), exposed_comm_ms=round((with_comm - without) * 1e3, 3))
+        print(f"[bench rank {rank}] {json.dumps(dp)}", file=sys.stderr, flush=True)
 
     N = (args.img // args.patch) ** 2
     Pd = 3 * args.patch * args.patch
@@ -198,9 +251,16 @@ def main():
         torch.cuda.synchronize()
         recs, ops.PROFILE = ops.PROFILE, None
         fam = {}
-        for label, flops, e0, e1 in recs:
+        hbm = {}
+        for label, flops, e0, e1, nbytes in recs:
             ms = e0.elapsed_time(e1)
             k = label.split("[")[0].split(" ")[0]
+            if nbytes:                                      # HBM-bound kernels: algorithmic bytes / time vs the 8 TB/s spec
+                h = hbm.setdefault(k, [0.0, 0.0, 0])
+                h[0] += nbytes
+                h[1] += ms
+                h[2] += 1
+                continue
             a = fam.setdefault(k, [0.0, 0.0, 0])
             a[0] += flops
             a[1] += ms
@@ -220,12 +280,10 @@ def main():
                     "launches_per_step": cnt, "avg_launch_ms": round(ms / cnt, 4),
                     "alg_flops_per_launch": fl / cnt,
                     "families": {k: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1), "ms_per_step": round(v[1], 3), "launches": v[2]}
-                                 for k, v in fam.items()}}
-
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        torch.set_num_threads(host_threads)
-        cpu = cpu_baseline(cfg, args.img, args.patch, args.mask_ratio)
+                                 for k, v in fam.items()},
+                    "hbm": {k: {"achieved_tbs": round(v[0] / (v[1] * 1e-3) / 1e12, 2), "peak_tbs": PEAK_HBM_TBS,
+                                "frac": round(v[0] / (v[1] * 1e-3) / 1e12 / PEAK_HBM_TBS, 3), "ms_per_step": round(v[1], 3),
+                                "launches": v[2], "alg_bytes_per_launch": round(v[0] / v[2])} for k, v in hbm.items()}}
 
     if rank == 0:
         out = {
@@ -242,6 +300,8 @@ def main():
             "final_loss": round(final_loss, 5),
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if dp is not None:
+            out["data_parallel"] = dp
         if os.environ.get("BENCH_KERNELS"):
             out["kernels"] = {k: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1), "ms": round(v[1], 3), "n": v[2]} for k, v in kernels.items()}
         print(json.dumps(out))

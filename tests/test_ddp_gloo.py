@@ -2,6 +2,8 @@
 gradient reducer (bucketing, range merging, sum + 1/world scale), the rank-0 weight
 broadcast over the flat parameter buffer, and rank-local mask streams."""
 import os
+
+import pytest
 import socket
 import sys
 
@@ -106,3 +108,28 @@ def test_single_process_reducer_is_a_noop():
     red.ready(0, 1000)
     red.finish()
     assert torch.equal(g, torch.arange(1000, dtype=torch.float32)) and red.grad_scale == 1.0
+
+
+def test_reducer_refuses_missing_or_repeated_ranges():
+    """finish() checks that one backward handed over every gradient range exactly once."""
+    sys.path.insert(0, os.path.join(ROOT, "vit-ssl_amd"))
+    from vitssl_hip import VitsslError
+    from vitssl_hip.engine import GradReducer
+    g = torch.zeros(4096)
+    red = GradReducer(g, bucket_mb=0.001)
+    red.begin()
+    red.ready(2048, 4096)
+    red.ready(0, 1024)
+    with pytest.raises(VitsslError, match="never handed"):
+        red.finish()
+    red.begin()
+    red.ready(2000, 4096)
+    red.ready(1024, 2048)
+    red.ready(0, 1024)
+    with pytest.raises(VitsslError, match="reduced twice"):
+        red.finish()
+    red.begin()
+    for lo, hi in ((3000, 4096), (1000, 2990), (0, 1000)):      # gaps smaller than the 64-element alignment padding are fine
+        red.ready(lo, hi)
+    red.finish()
+    assert red.stats() == (len(red.launched), 4 * (1096 + 1990 + 1000))

@@ -205,3 +205,24 @@ def test_dino_two_ranks_share_one_centre(tmp_path):
     world = 2
     mp.spawn(_dino_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"dino_ok{r}").exists() for r in range(world))
+
+
+def test_bench_two_rank_path_reports_its_collectives(tmp_path):
+    """bench.py's N > 1 path, rehearsed with two ranks on one GPU (gloo rendezvous, --share-gpu): the
+    JSON line carries the self-diagnosis block (world size as the collective sees it, buckets, exposed
+    communication) the first real multi-GPU run will be read by."""
+    import json
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--model", "vit_tiny", "--batch", "8", "--img", "64", "--backend", "gloo", "--share-gpu", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["scaling"] == "weak"
+    dp = d["data_parallel"]
+    assert dp["world_size"] == 2 and dp["allreduce_of_ones"] == 2.0 and dp["backend"] == "gloo"
+    assert dp["buckets_per_step"] >= 1 and dp["reduced_bytes_per_step"] >= 0.99 * dp["grad_bytes"] - 64 * 4 * 200
+    assert "exposed_comm_ms" in dp and d["roofline"]["hbm"]["ln_fwd"]["launches"] > 0

@@ -15,6 +15,8 @@
 // slabs into C (fp32 atomics cost ~50 us per workgroup at the chip's 1.3 TB/s atomic
 // rate; they remain as the fallback when no workspace is given).  Rows past M are
 // zero-filled by the buffer descriptor's bounds check, so ragged M needs no tail code.
+#include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -155,6 +157,240 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(TnParams p) {
   }
 }
 
+// ====================================================================================
+// Ping-pong main loop for the weight-gradient GEMM (same scheme as gemm_nt_pp_kernel, see there).
+// A K-tile (64 contraction rows) is multiplied in 4 phases of 16 MFMAs: (ks, n1-half) =
+// (0,0) (0,1) (1,0) (1,1); waves 4-7 run one barrier behind waves 0-3, so each SIMD always has one
+// wave in its MFMA cluster and one reading fragments / issuing DMA.  Staging units are the 32-row
+// halves of the two operand tiles (16 KiB = 2 wave-instructions per wave):
+//     p0: Bk1(t+1)   p1: Ak1(t+1) + vmcnt(8)   p2: Bk0(t+2)   p3: Ak0(t+2) + vmcnt(8)
+// (a half is refilled two phases after its last fragment read: Bk0 is read in p0, Ak0 in p0-p1, Bk1 in
+// p2, Ak1 in p2-p3; the wait covering a half sits in the phase before its first read).
+typedef __attribute__((ext_vector_type(8))) short tn_s16x8;
+
+template <int N>
+__device__ __forceinline__ void tn_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ void tn_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, unsigned voffset) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_wave_base), 16, voffset, 0, 0, 0);
+}
+
+template <int IMM>
+__device__ __forceinline__ void tn_ds_tr(s16x4& dst, unsigned addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(IMM));
+}
+
+__device__ __forceinline__ void tn_section() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("" ::: "memory");
+}
+
+__global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_pp_kernel(TnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BUF = 2 * TN_TILE_BYTES;               // one K-tile: A tile then B tile
+  constexpr unsigned OOBV = 0x80000000u;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int w1 = wave >> 2, w2 = wave & 3;
+
+  const int ntiles = p.tiles1 * p.tiles2;
+  const int nwg = ntiles * p.splits;
+  const int xcd = blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7;
+  const int bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
+  const int split = bid / ntiles;
+  const int tile = bid - split * ntiles;
+  const int t1 = tile / p.tiles2, t2 = tile - t1 * p.tiles2;
+  const int c1 = t1 * TN_T, c2 = t2 * TN_T;
+
+  const long long total_chunks = (p.M + TN_KM - 1) / TN_KM;
+  const long long ch_begin = (long long)split * p.chunks_per_split;
+  long long ch_end = ch_begin + p.chunks_per_split;
+  if (ch_end > total_chunks) ch_end = total_chunks;
+  const int nk = ch_begin < ch_end ? (int)(ch_end - ch_begin) : 0;   // empty split: writes a zero slab
+
+  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((unsigned long long)p.M * p.N1 * 2ull), 0x00020000);
+  __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)((unsigned long long)p.M * p.N2 * 2ull), 0x00020000);
+
+  // staging slots of this wave: unit X_kh = rows 32 h + [0, 32) of the operand tile; slot e covers rows
+  // 32 h + 4 wave + 2 e + (lane >> 5)
+  unsigned voffA[2][2], voffB[2][2];
+  int ldsA[2][2], ldsB[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int r0 = 32 * h + 4 * wave + 2 * e;
+      const int row = r0 + (lane >> 5);
+      const int ch16 = lane & 31;
+      const int sch16 = (((ch16 >> 1) ^ tn_f(row)) << 1) | (ch16 & 1);
+      voffA[h][e] = (unsigned)((row * (long long)p.N1 + c1) * 2 + sch16 * 16);
+      voffB[h][e] = (unsigned)((row * (long long)p.N2 + c2) * 2 + sch16 * 16);
+      ldsA[h][e] = r0 * 512;
+      ldsB[h][e] = TN_TILE_BYTES + r0 * 512;
+    }
+  const unsigned stepA = (unsigned)TN_KM * (unsigned)p.N1 * 2u, stepB = (unsigned)TN_KM * (unsigned)p.N2 * 2u;
+  // byte offset of K-tile t's first row (OOBV past the end of this workgroup's range: zero fill, no traffic)
+  auto baseA = [&](int t) -> unsigned { return t < nk ? (unsigned)(ch_begin + t) * stepA : OOBV; };
+  auto baseB = [&](int t) -> unsigned { return t < nk ? (unsigned)(ch_begin + t) * stepB : OOBV; };
+  auto stage_a = [&](int t, int bufsel, auto h_c) {
+    constexpr int h = decltype(h_c)::value;
+    const unsigned b = baseA(t);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) tn_dma16(rsA, smem + bufsel * BUF + ldsA[h][e], voffA[h][e] + b);
+  };
+  auto stage_b = [&](int t, int bufsel, auto h_c) {
+    constexpr int h = decltype(h_c)::value;
+    const unsigned b = baseB(t);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) tn_dma16(rsB, smem + bufsel * BUF + ldsB[h][e], voffB[h][e] + b);
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // Fragment reads are inline asm: for the ds_read_tr builtin (no memory operand) hipcc assumes a
+  // dependency on every LDS-DMA in flight and drains vmcnt(0) before each read, which serialises the
+  // staging with the arithmetic (that is what held the two-phase loop at ~0.85 PF).  The asm reads land
+  // in 64-bit temporaries; the 128-bit MFMA operands are assembled only after the explicit
+  // s_waitcnt lgkmcnt(0) that follows the phase's first barrier, so no instruction touches a destination
+  // register before its data has arrived.
+  const unsigned lds0 = (unsigned)(unsigned long long)LDS_PTR(smem);
+  unsigned fragA[8], fragB[4];                         // per-lane byte address of (ks 0, rows r0) of every 16-column tile
+  {
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp_ = lane & 3;
+    const int r0 = 8 * g + q;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fragA[i] = lds0 + r0 * 512 + (((w1 * 8 + i) ^ tn_f(r0)) << 5) + 8 * pp_;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fragB[j] = lds0 + TN_TILE_BYTES + r0 * 512 + (((w2 * 4 + j) ^ tn_f(r0)) << 5) + 8 * pp_;
+  }
+  s16x4 ta[4][2], tb[4][2];                            // raw halves (rows r0.., rows r0 + 4..) of the fragments being read
+  bf16x8 fa[4], fb[4];
+  auto read_b = [&](int bufoff, auto ks_c) {
+    constexpr int ks = decltype(ks_c)::value;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned a = fragB[j] + (unsigned)bufoff;
+      tn_ds_tr<ks * 16384>(tb[j][0], a);
+      tn_ds_tr<ks * 16384 + 2048>(tb[j][1], a);
+    }
+  };
+  auto read_a = [&](int bufoff, auto ks_c, auto ih_c) {
+    constexpr int ks = decltype(ks_c)::value, ih = decltype(ih_c)::value;
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+      const unsigned a = fragA[4 * ih + ii] + (unsigned)bufoff;
+      tn_ds_tr<ks * 16384>(ta[ii][0], a);
+      tn_ds_tr<ks * 16384 + 2048>(ta[ii][1], a);
+    }
+  };
+  auto landed = [&](bool with_b) {                     // after the barrier: wait for the reads, assemble the operands
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (with_b) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const tn_s16x8 v = {tb[j][0][0], tb[j][0][1], tb[j][0][2], tb[j][0][3], tb[j][1][0], tb[j][1][1], tb[j][1][2], tb[j][1][3]};
+        fb[j] = __builtin_bit_cast(bf16x8, v);
+      }
+    }
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+      const tn_s16x8 v = {ta[ii][0][0], ta[ii][0][1], ta[ii][0][2], ta[ii][0][3], ta[ii][1][0], ta[ii][1][1], ta[ii][1][2], ta[ii][1][3]};
+      fa[ii] = __builtin_bit_cast(bf16x8, v);
+    }
+  };
+  auto mma = [&](auto ih_c) {
+    constexpr int ih = decltype(ih_c)::value;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[4 * ih + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[ii], acc[4 * ih + ii][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+
+  if (nk > 0) {
+    stage_b(0, 0, I0{});
+    stage_a(0, 0, I0{});
+    stage_b(0, 0, I1{});
+    stage_a(0, 0, I1{});
+    stage_b(1, 1, I0{});
+    stage_a(1, 1, I0{});
+    tn_wait_vmcnt<8>();                                // Bk0, Ak0 of K-tile 0 have landed
+    tn_section();
+    if (w1 == 1) tn_section();                         // waves 4-7 run one barrier behind waves 0-3
+    int buf = 0;
+    for (int t = 0; t < nk; ++t) {
+      const int cur = buf * BUF;
+      // p0: ks 0, n1 tiles 0-3
+      read_b(cur, I0{});
+      read_a(cur, I0{}, I0{});
+      stage_b(t + 1, buf ^ 1, I1{});
+      tn_section();
+      landed(true);
+      mma(I0{});
+      tn_section();
+      // p1: ks 0, n1 tiles 4-7
+      read_a(cur, I0{}, I1{});
+      stage_a(t + 1, buf ^ 1, I1{});
+      tn_wait_vmcnt<8>();
+      tn_section();
+      landed(false);
+      mma(I1{});
+      tn_section();
+      // p2: ks 1, n1 tiles 0-3
+      read_b(cur, I1{});
+      read_a(cur, I1{}, I0{});
+      stage_b(t + 2, buf, I0{});
+      tn_section();
+      landed(true);
+      mma(I0{});
+      tn_section();
+      // p3: ks 1, n1 tiles 4-7
+      read_a(cur, I1{}, I1{});
+      stage_a(t + 2, buf, I0{});
+      tn_wait_vmcnt<8>();
+      tn_section();
+      landed(false);
+      mma(I1{});
+      if (!(t + 1 == nk && w1 == 1)) tn_section();
+      buf ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing zero-fill DMA retired before the LDS is released
+  }
+
+  float* dst = p.slabs ? p.slabs + (long long)split * p.N1 * p.N2 : p.C;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int n1 = c1 + w1 * 128 + i * 16 + (lane & 15);
+    if (n1 >= p.N1) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n2 = c2 + w2 * 64 + j * 16 + 4 * (lane >> 4);
+      if (n2 >= p.N2) continue;
+      float* q = dst + (long long)n1 * p.N2 + n2;
+      if (p.slabs) {
+        *(f32x4*)q = acc[i][j];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) unsafeAtomicAdd(q + r, acc[i][j][r]);
+      }
+    }
+  }
+}
+
 // C[e] += sum_s slabs[s][e]
 __global__ void tn_reduce_kernel(float* __restrict__ C, const float* __restrict__ slabs, long long n4, long long stride, int splits) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
@@ -204,8 +440,15 @@ extern "C" int vitssl_gemm_bf16_tn(const void* A, const void* B, float* C, int64
   p.slabs = (workspace && workspace_floats >= need) ? workspace : nullptr;
   VS_CHECK_ARG(!workspace || p.slabs, "gemm_tn: workspace too small (%lld < %lld floats)", (long long)workspace_floats, need);
   static bool attr_done = false;
+  static int use_pp = -1;                              // VITSSL_TN_PP=0: the two-phase loop (developer knob)
+  if (use_pp < 0) {
+    const char* e = getenv("VITSSL_TN_PP");
+    use_pp = e ? atoi(e) : 1;
+  }
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)gemm_tn_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
     if (e != hipSuccess) {
       vitssl_set_error("gemm_tn: cannot raise dynamic LDS: %s", hipGetErrorString(e));
       return VITSSL_ERR_LAUNCH;
@@ -213,7 +456,10 @@ extern "C" int vitssl_gemm_bf16_tn(const void* A, const void* B, float* C, int64
     attr_done = true;
   }
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tiles1 * p.tiles2 * p.splits), dim3(TN_THREADS), TN_LDS_BYTES, s, p);
+  if (use_pp)
+    hipLaunchKernelGGL(gemm_tn_pp_kernel, dim3(p.tiles1 * p.tiles2 * p.splits), dim3(TN_THREADS), TN_LDS_BYTES, s, p);
+  else
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tiles1 * p.tiles2 * p.splits), dim3(TN_THREADS), TN_LDS_BYTES, s, p);
   VS_CHECK_LAUNCH("gemm_tn");
   if (p.slabs) {
     const long long n4 = (long long)N1 * N2 / 4;

@@ -182,7 +182,10 @@ class GradReducer:
     >= `bucket_elems` and all-reduced (sum) on a side stream.  The 1/world factor is
     folded into the optimizer kernel.  On CPU tensors (gloo, tests) it runs inline."""
 
-    def __init__(self, gflat: torch.Tensor, group=None, bucket_mb: float = 32.0):
+    def __init__(self, gflat: torch.Tensor, group=None, bucket_mb: float = 32.0, expect: Optional[Tuple[int, int]] = None):
+        """`expect` = (lo, hi) range of the flat buffer that one backward must hand over exactly once
+        (default: the whole buffer); finish() checks it, so a schedule change that forgets or repeats a
+        range fails loudly on one GPU instead of silently de-synchronising replicas on eight."""
         import torch.distributed as dist
         self.dist = dist
         self.gflat = gflat
@@ -195,6 +198,8 @@ class GradReducer:
         self.cuda = gflat.is_cuda
         self.comm_stream = torch.cuda.Stream(device=gflat.device) if self.cuda else None
         self.launched: List[Tuple[int, int]] = []
+        self.expect = expect if expect is not None else (0, gflat.numel())
+        self.check_coverage = True
 
     def _flush(self):
         if not self.pending:
@@ -237,6 +242,25 @@ class GradReducer:
         self.handles = []
         if self.cuda and self.world > 1:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if self.check_coverage:
+            self._assert_covered()
+
+    def _assert_covered(self):
+        """Every element of the expected range was handed over exactly once (alignment padding between
+        parameters may be skipped: it is never read)."""
+        pos = self.expect[0]
+        for lo, hi in sorted(self.launched):
+            if lo < pos:
+                raise L.VitsslError(f"GradReducer: gradient range [{lo}, {hi}) was reduced twice (previous range ended at {pos})")
+            if lo - pos >= ALIGN:
+                raise L.VitsslError(f"GradReducer: gradient range [{pos}, {lo}) was never handed to the reducer")
+            pos = hi
+        if self.expect[1] - pos >= ALIGN:
+            raise L.VitsslError(f"GradReducer: gradient range [{pos}, {self.expect[1]}) was never handed to the reducer")
+
+    def stats(self):
+        """(number of buckets, bytes) of the last step."""
+        return len(self.launched), 4 * sum(hi - lo for lo, hi in self.launched)
 
     @property
     def grad_scale(self) -> float:

@@ -45,8 +45,9 @@ def make_dropout(p=0.0, seed=0, site=0):
 
 NO_DROP = make_dropout()
 
-# Optional live kernel timing (bench.py): when PROFILE is a list, every GEMM launch is
-# bracketed by HIP events ON THE LAUNCH STREAM and (label, flops, start, end) appended.
+# Optional live kernel timing (bench.py): when PROFILE is a list, every GEMM / attention launch and
+# the HBM-bound kernels (LayerNorm, AdamW) are bracketed by HIP events ON THE LAUNCH STREAM and
+# (label, flops, start, end, algorithmic_bytes) appended.
 PROFILE = None
 
 
@@ -58,12 +59,12 @@ def _prof_begin():
     return ev
 
 
-def _prof_end(ev0, label, flops):
+def _prof_end(ev0, label, flops, nbytes=0):
     if ev0 is None:
         return
     ev1 = torch.cuda.Event(enable_timing=True)
     ev1.record(torch.cuda.current_stream())
-    PROFILE.append((label, flops, ev0, ev1))
+    PROFILE.append((label, flops, ev0, ev1, nbytes))
 
 
 def dropout_mask(rows, cols, drop, device):
@@ -74,17 +75,22 @@ def dropout_mask(rows, cols, drop, device):
 
 def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps=1e-5):
     rows, cols = x.shape
+    ev = _prof_begin()
     call("vitssl_layernorm_fwd", _chk(x, F32, "x"), _chk(gamma, F32, "gamma", (cols,)), _chk(beta, F32, "beta", (cols,)),
          _chk(y, BF16, "y", (rows, cols)), _chk(mean, F32, "mean", (rows,)), _chk(rstd, F32, "rstd", (rows,)),
          rows, cols, float(eps), _stream())
+    _prof_end(ev, "ln_fwd", 0.0, rows * (6 * cols + 8))          # x fp32 in, y bf16 out, mean / rstd
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, g_res, g_out, gm, dgamma, dbeta, gm_colsum=None, drop=NO_DROP):
     rows, cols = x.shape
+    ev = _prof_begin()
     call("vitssl_layernorm_bwd", _chk(dy, BF16, "dy", (rows, cols)), _chk(x, F32, "x"), _chk(mean, F32, "mean", (rows,)),
          _chk(rstd, F32, "rstd", (rows,)), _chk(gamma, F32, "gamma", (cols,)), _opt(g_res, F32, "g_res", (rows, cols)),
          _chk(g_out, F32, "g_out", (rows, cols)), _opt(gm, BF16, "gm", (rows, cols)), _chk(dgamma, F32, "dgamma", (cols,)),
          _chk(dbeta, F32, "dbeta", (cols,)), _opt(gm_colsum, F32, "gm_colsum", (cols,)), drop, rows, cols, _stream())
+    # dy bf16 + x fp32 (+ residual gradient fp32) in, gradient fp32 (+ masked bf16 operand) out
+    _prof_end(ev, "ln_bwd", 0.0, rows * (cols * (2 + 4 + (4 if g_res is not None else 0) + 4 + (2 if gm is not None else 0)) + 8))
 
 
 def grad_mask_cast(g, gm, gm_colsum=None, drop=NO_DROP):
@@ -297,8 +303,10 @@ class CastPlan:
 
 def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step, gscale=1.0):
     n = p.numel()
+    ev = _prof_begin()
     call("vitssl_adamw", _chk(p, F32, "p"), _chk(g, F32, "g", p.shape), _chk(m, F32, "m", p.shape), _chk(v, F32, "v", p.shape),
          n, float(lr), float(beta1), float(beta2), float(eps), float(wd), int(step), float(gscale), _stream())
+    _prof_end(ev, "adamw", 0.0, 28 * n)                          # p, m, v read + written, g read
 
 
 def ema(teacher, student, m):
