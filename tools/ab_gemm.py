@@ -27,7 +27,53 @@ def load(name):
     lib.vitssl_last_error.restype = C.c_char_p
     lib.vitssl_gemm_bf16_nt.argtypes = [C.POINTER(L.Gemm), C.c_void_p]
     lib.vitssl_gemm_bf16_nt.restype = C.c_int
+    lib.vitssl_gemm_bf16_tn.argtypes = L.PROTOTYPES["vitssl_gemm_bf16_tn"]
+    lib.vitssl_gemm_bf16_tn.restype = C.c_int
+    lib.vitssl_gemm_tn_workspace_floats.restype = C.c_int64
+    lib.vitssl_gemm_tn_workspace_floats.argtypes = [C.c_int64, C.c_int, C.c_int]
     return lib
+
+
+def tn_mode(names, libs, M, rounds, iters, st):
+    """C[N1,N2] += A[M,N1]^T B[M,N2] (weight gradients); SHAPES="N1,N2;..." """
+    shapes = [(768, 768), (2304, 768), (3072, 768), (768, 3072)]
+    if os.environ.get("SHAPES"):
+        shapes = [tuple(int(v) for v in sk.split(",")) for sk in os.environ["SHAPES"].split(";")]
+    rb = lambda *s: (torch.randn(*s, device=DEV) * 0.5).to(torch.bfloat16)  # noqa: E731
+    for (N1, N2) in shapes:
+        A, B = rb(M, N1), rb(M, N2)
+        Cm = torch.zeros(N1, N2, device=DEV)
+        wsn = int(libs[0].vitssl_gemm_tn_workspace_floats(M, N1, N2))
+        ws = torch.empty(max(wsn, 1), device=DEV)
+
+        def run(lib):
+            rc = lib.vitssl_gemm_bf16_tn(A.data_ptr(), B.data_ptr(), Cm.data_ptr(), M, N1, N2, ws.data_ptr(), ws.numel(), st)
+            if rc != 0:
+                raise RuntimeError(lib.vitssl_last_error().decode())
+
+        for lib in libs:
+            run(lib)
+            run(lib)
+        torch.cuda.synchronize()
+        times = [[] for _ in libs]
+        for _ in range(rounds):
+            for li, lib in enumerate(libs):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(iters):
+                    run(lib)
+                e1.record()
+                times[li].append((e0, e1))
+        torch.cuda.synchronize()
+        fl = 2.0 * M * N1 * N2
+        line = f"tn {N1}x{N2}x{M}"
+        base = None
+        for li in range(len(libs)):
+            ts = sorted(a.elapsed_time(b) / iters * 1e3 for a, b in times[li])
+            m = ts[len(ts) // 2]
+            base = base or m
+            line += f" | {names[li]} {m:7.1f} us (min {ts[0]:6.1f}) {fl / m / 1e6:6.0f} TF/s x{m / base:.3f}"
+        print(line, flush=True)
 
 
 def main():
@@ -43,6 +89,8 @@ def main():
     rb = lambda *s: (torch.randn(*s, device=DEV) * 0.5).to(torch.bfloat16)  # noqa: E731
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     print("variants:", " ".join(names), flush=True)
+    if os.environ.get("MODE") == "tn":
+        return tn_mode(names, libs, M, rounds, iters, st)
     for (N, K) in shapes:
         A, B = rb(M, K), rb(N, K)
         bias = torch.randn(N, device=DEV)

@@ -17,8 +17,10 @@ if kind == "nt":
     out1 = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
     aux = torch.randn(M, N, device=dev) if epi == 3 else rb(M, N)
     bias = torch.randn(N, device=dev)
+    drop = ops.make_dropout(0.1, 1, 2) if (epi in (2, 3) and not os.environ.get("NODROP")) else ops.NO_DROP   # as in the model
+    cs = torch.zeros(N, device=dev) if epi == 4 else None
     for _ in range(6):
-        ops.gemm_nt(A, B, out, epi, bias=bias, aux=aux if epi in (3, 4) else None, out1=out1 if epi == 2 else None)
+        ops.gemm_nt(A, B, out, epi, bias=bias, aux=aux if epi in (3, 4) else None, out1=out1 if epi == 2 else None, drop=drop, colsum=cs)
 else:
     A, B = rb(M, N), rb(M, K)
     C = torch.zeros(N, K, device=dev)

@@ -38,6 +38,11 @@
 #ifndef NT_STORE_AUX
 #define NT_STORE_AUX 0
 #endif
+// residual-stream stores (fp32, read next by a different kernel) are issued non-temporal: interleaved A/B
+// on MI355X, out-projection shape M = 50176, N = K = 768: 116 -> 97 us; neutral at K = 3072
+#ifndef NT_RESID_AUX
+#define NT_RESID_AUX 2
+#endif
 // 1: every epilogue load / store instruction touches 8 rows x 128 bytes (whole cache lines; lanes
 // r and r^8 of a 16-lane row exchange halves with a DPP rotate) instead of 16 rows x 64 bytes
 #ifndef NT_ROWS128
@@ -47,6 +52,10 @@
 // 2 = stores but no GELU / dropout arithmetic and no residual / g' loads
 #ifndef NT_ABLATE
 #define NT_ABLATE 0
+#endif
+// diagnostic builds only: ping-pong K loop without 1 = DMA, 2 = fragment reads, 3 = MFMA
+#ifndef NT_LOOP_ABLATE
+#define NT_LOOP_ABLATE 0
 #endif
 
 namespace {
@@ -241,6 +250,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
     }
   };
   // one pair (32 columns) of a row tile of an fp32 image
+  constexpr int F32_AUX = NT_STORE_AUX != 0 ? NT_STORE_AUX : (EPI == VITSSL_EPI_RESID ? NT_RESID_AUX : 0);
   auto store_f32_pair = [&](__amdgpu_buffer_rsrc_t rs, int i, int jp, const f32x4& v0, const f32x4& v1, const int (&nnp)[2]) {
     if (NT_ABLATE == 1) {
       asm volatile("" ::"v"(v0), "v"(v1));
@@ -249,11 +259,11 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
     if (NT_ROWS128) {
       u32x4 s1, s2;
       to_lines(__builtin_bit_cast(u32x4, v0), __builtin_bit_cast(u32x4, v1), s1, s2);
-      __builtin_amdgcn_raw_buffer_store_b128(s1, rs, off_f32_line(i, jp, 0), 0, NT_STORE_AUX);
-      __builtin_amdgcn_raw_buffer_store_b128(s2, rs, off_f32_line(i, jp, 1), 0, NT_STORE_AUX);
+      __builtin_amdgcn_raw_buffer_store_b128(s1, rs, off_f32_line(i, jp, 0), 0, F32_AUX);
+      __builtin_amdgcn_raw_buffer_store_b128(s2, rs, off_f32_line(i, jp, 1), 0, F32_AUX);
     } else {
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), rs, off_elem(i, nnp[0], 4u), 0, NT_STORE_AUX);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), rs, off_elem(i, nnp[1], 4u), 0, NT_STORE_AUX);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), rs, off_elem(i, nnp[0], 4u), 0, F32_AUX);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), rs, off_elem(i, nnp[1], 4u), 0, F32_AUX);
     }
   };
   __amdgpu_buffer_rsrc_t rsOut0, rsOut1, rsAux;
@@ -782,6 +792,7 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_nt_pp_kernel(NtParams p)
   // DMA of one unit: 2 wave-instructions.  bufsel = LDS buffer (0/1) of the unit's K-tile.
   auto stage_a = [&](const Cur& c, int bufsel, auto h_c) {
     constexpr int h = decltype(h_c)::value;
+    if (NT_LOOP_ABLATE == 1 && bufsel >= 0) return;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const bool live = ldsA[h][e] != DUMMY;
@@ -791,6 +802,7 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_nt_pp_kernel(NtParams p)
   };
   auto stage_b = [&](const Cur& c, int bufsel, auto h_c) {
     constexpr int h = decltype(h_c)::value;
+    if (NT_LOOP_ABLATE == 1 && bufsel >= 0) return;
 #pragma unroll
     for (int e = 0; e < 2; ++e)
       dma16_to_lds(rsB, smem + bufsel * BUF + ldsB[h][e], voffB[h][e] + c.b);
@@ -812,6 +824,7 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_nt_pp_kernel(NtParams p)
   auto read_a = [&](const char* buf, auto mh_c) {
     constexpr int mh = decltype(mh_c)::value;
     constexpr int cnt = mh == 0 ? 4 : MH1;
+    if (NT_LOOP_ABLATE == 2 && buf != nullptr) return;
 #pragma unroll
     for (int ii = 0; ii < cnt; ++ii) {
       fa[0][ii] = *(const bf16x8*)(buf + offA0 + (4 * mh + ii) * 2048);
@@ -820,6 +833,7 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_nt_pp_kernel(NtParams p)
   };
   auto read_b = [&](const char* buf, auto nh_c) {
     constexpr int nh = decltype(nh_c)::value;
+    if (NT_LOOP_ABLATE == 2 && buf != nullptr) return;
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       fb[nh][0][jj] = *(const bf16x8*)(buf + offB0 + (2 * nh + jj) * 2048);
@@ -829,6 +843,11 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_nt_pp_kernel(NtParams p)
   auto mma_quad = [&](auto mh_c, auto nh_c) {
     constexpr int mh = decltype(mh_c)::value, nh = decltype(nh_c)::value;
     constexpr int cnt = mh == 0 ? 4 : MH1;
+    if (NT_LOOP_ABLATE == 3) {
+      asm volatile("" ::"v"(fa[0][0]), "v"(fa[1][0]), "v"(fa[0][1]), "v"(fa[1][1]), "v"(fa[0][2]), "v"(fa[1][2]), "v"(fa[0][3]), "v"(fa[1][3]),
+                   "v"(fb[nh][0][0]), "v"(fb[nh][1][0]), "v"(fb[nh][0][1]), "v"(fb[nh][1][1]));
+      return;
+    }
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
@@ -1005,7 +1024,13 @@ int launch_cfg(NtParams p, hipStream_t s) {
   p.tiles_m = (int)ceil_div64(p.M, CFG::BM);
   p.tiles_n = (int)ceil_div64(p.N, CFG::BN);
   const int want = (int)((2 * 1024 * 1024) / ((long long)CFG::BN * p.K * 2));   // panels of a group <= ~2 MiB of L2
-  if (p.tiles_n <= 4) p.group_n = p.tiles_n;
+  static int group_knob = -1;                          // VITSSL_NT_GROUPN: force the raster group width (developer knob)
+  if (group_knob < 0) {
+    const char* e = getenv("VITSSL_NT_GROUPN");
+    group_knob = e ? atoi(e) : 0;
+  }
+  if (group_knob > 0) p.group_n = group_knob < p.tiles_n ? group_knob : p.tiles_n;
+  else if (p.tiles_n <= 4) p.group_n = p.tiles_n;
   else if (want <= 2) p.group_n = 2;
   else if (p.tiles_n % 6 == 0 && want >= 6) p.group_n = 6;
   else if (p.tiles_n % 4 == 0) p.group_n = 4;
