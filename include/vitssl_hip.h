@@ -16,7 +16,9 @@
  *     synchronises the device
  *   - bf16 tensors are passed as void* (raw uint16 storage), fp32 as float*
  *   - all matrices are dense row-major; "ld" is always the logical column count
- *   - re-entrant: no global mutable state (safe from autograd's backward thread)
+ *   - callable from any host thread (autograd's backward thread included): the only process-wide
+ *     state are idempotent "attribute set" / "knob read" flags and the last-error string, which is
+ *     thread-local; one process drives one GPU (launches go to the CURRENT device's stream)
  */
 #ifndef VITSSL_HIP_H
 #define VITSSL_HIP_H
@@ -129,7 +131,8 @@ int vitssl_gemm_bf16_tn(const void* A, const void* B, float* C, int64_t M, int N
  * out  bf16 [B, N, H*dh]      (heads merged, ready for final_linear)
  * lse  f32  [B, H, N]         (log-sum-exp of the scaled scores, saved for backward)
  * probs f32 [B, H, N, N] or NULL (return_attn=True path)
- * dh in {32, 64, 128}; scale = 1/sqrt(dh). */
+ * dh = 64 (every ViT family of BASELINE.json), N <= 256; other geometries return VITSSL_ERR_ARG;
+ * scale = 1/sqrt(dh). */
 int vitssl_attn_fwd(const void* qkv, void* out, float* lse, float* probs, int B, int N, int H, int dh,
                     void* stream);
 /* delta_ws: f32 [B,H,N] scratch for rowsum(dO*O) (used by the two-launch variant only; the default

@@ -20,10 +20,11 @@
 // (ds_read_b64_tr_b16): 128-byte rows, 16-byte chunk index XORed with ((row>>1)&3)<<1;
 // both read kinds are bank-conflict free.
 //
-// Backward = 2 launches: dQ (each wave owns pairs of 16-query tiles, sweeps keys; it also
-// produces delta = rowsum(dO*O) for its queries from the fragments it already holds) and
-// dK/dV (each wave owns 32 keys, sweeps queries).  P is recomputed from the saved
-// log-sum-exp; nothing of size N^2 ever reaches HBM.
+// Backward = ONE launch (attn_bwd_fused_kernel): wave w owns keys 32w .. 32w+31 (dK / dV accumulators),
+// sweeps the queries, drops every dS tile into an LDS exchange image from which the waves contract dQ;
+// delta = rowsum(dO*O) is computed in its prologue.  P is recomputed from the saved log-sum-exp; nothing
+// of size N^2 ever reaches HBM.  The older two-launch form (attn_bwd_dq_kernel + attn_bwd_dkv_kernel)
+// stays behind VITSSL_ATTN_BWD=split for A/B timing.
 #include <stdlib.h>
 #include "common.h"
 

@@ -43,6 +43,12 @@
 #ifndef NT_RESID_AUX
 #define NT_RESID_AUX 2
 #endif
+// bf16 images (activations / gradients consumed by the NEXT kernel): 16 = sc1, write-through without keeping
+// the line in this XCD's L2, so the 30-60 MB of output per tile round do not evict the weight panels the
+// following rounds re-use (FETCH_SIZE of the FC1 GELU launch 362 -> 297 MB at group 4, 223 MB at group 6)
+#ifndef NT_BF16_AUX
+#define NT_BF16_AUX 0
+#endif
 // 1: every epilogue load / store instruction touches 8 rows x 128 bytes (whole cache lines; lanes
 // r and r^8 of a 16-lane row exchange halves with a DPP rotate) instead of 16 rows x 64 bytes
 #ifndef NT_ROWS128
@@ -224,6 +230,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
     return u32x4{lo[0], hi[0], lo[1], hi[1]};
   };
   // one row tile of a bf16 image: w[jp][h]
+  constexpr int BF16_AUX = NT_STORE_AUX != 0 ? NT_STORE_AUX : NT_BF16_AUX;
   auto store_bf16_row = [&](__amdgpu_buffer_rsrc_t rs, int i, const u32x2 (&w)[2][2]) {
     if (NT_ABLATE == 1) {
       asm volatile("" ::"v"(w[0][0]), "v"(w[0][1]), "v"(w[1][0]), "v"(w[1][1]));
@@ -234,18 +241,18 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
       if (NT_ROWS128) {
         u32x4 s1, s2;
         to_lines(a, b, s1, s2);
-        __builtin_amdgcn_raw_buffer_store_b128(s1, rs, off_bf16_line(i, 0), 0, NT_STORE_AUX);
-        __builtin_amdgcn_raw_buffer_store_b128(s2, rs, off_bf16_line(i, 1), 0, NT_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(s1, rs, off_bf16_line(i, 0), 0, BF16_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(s2, rs, off_bf16_line(i, 1), 0, BF16_AUX);
       } else {
-        __builtin_amdgcn_raw_buffer_store_b128(a, rs, off_bf16_wide(i, 0), 0, NT_STORE_AUX);
-        __builtin_amdgcn_raw_buffer_store_b128(b, rs, off_bf16_wide(i, 1), 0, NT_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(a, rs, off_bf16_wide(i, 0), 0, BF16_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(b, rs, off_bf16_wide(i, 1), 0, BF16_AUX);
       }
     } else {
 #pragma unroll
       for (int jp = 0; jp < 2; ++jp) {
         const int na = n0 + wn * 64 + (2 * jp) * 16 + 4 * g4;
-        __builtin_amdgcn_raw_buffer_store_b64(w[jp][0], rs, off_elem(i, na, 2u), 0, NT_STORE_AUX);
-        __builtin_amdgcn_raw_buffer_store_b64(w[jp][1], rs, off_elem(i, na + 16, 2u), 0, NT_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b64(w[jp][0], rs, off_elem(i, na, 2u), 0, BF16_AUX);
+        __builtin_amdgcn_raw_buffer_store_b64(w[jp][1], rs, off_elem(i, na + 16, 2u), 0, BF16_AUX);
       }
     }
   };

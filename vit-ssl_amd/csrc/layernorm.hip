@@ -16,6 +16,17 @@ namespace {
 
 constexpr int LN_THREADS = 256;  // 4 waves = 4 rows in flight per block
 
+// 1: the residual-branch gradient of a row is requested together with dy and x (one memory round trip per row
+// instead of two: the second used to start only after the two wave reductions)
+#ifndef LN_HOIST_GRES
+#define LN_HOIST_GRES 1
+#endif
+// 1: forward stores 16 bytes per lane (adjacent lanes trade their v = 0 / v = 1 pieces with a DPP quad
+// swap, so an even lane writes 8 consecutive columns of the first 256, an odd lane of the second 256)
+#ifndef LN_FWD_PAIR
+#define LN_FWD_PAIR 0
+#endif
+
 template <int V>
 __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, bf16_t* __restrict__ y,
@@ -62,6 +73,25 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restr
       rstd[row] = rs;
     }
     bf16_t* yr = y + row * cols;
+    if (LN_FWD_PAIR && V >= 2 && c4n == 64 * V) {
+      u32x2 w[V];
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const f32x4 o = xv[v] * rs * g[v] + b[v];
+        w[v] = u32x2{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+      }
+      const bool odd = lane & 1;
+#pragma unroll
+      for (int v = 0; v + 1 < V; v += 2) {
+        const u32x2 t = odd ? w[v] : w[v + 1];                        // what the partner lane needs
+        const u32x2 r = {(unsigned)__builtin_amdgcn_update_dpp(0, (int)t[0], 0xB1, 0xF, 0xF, false),
+                         (unsigned)__builtin_amdgcn_update_dpp(0, (int)t[1], 0xB1, 0xF, 0xF, false)};   // quad_perm [1,0,3,2]
+        const u32x4 q = odd ? u32x4{r[0], r[1], w[v + 1][0], w[v + 1][1]} : u32x4{w[v][0], w[v][1], r[0], r[1]};
+        *(u32x4*)(yr + 256 * (v + (odd ? 1 : 0)) + 4 * (lane - (odd ? 1 : 0))) = q;
+      }
+      if (V & 1) *(u32x2*)(yr + 4 * (lane + 64 * (V - 1))) = w[V - 1];
+      continue;
+    }
 #pragma unroll
     for (int v = 0; v < V; ++v) {
       const int c4 = lane + 64 * v;
@@ -101,12 +131,14 @@ __global__ __launch_bounds__(LN_THREADS, (V <= 2 || (V == 3 && !HAS_CS)) ? 4 : (
     if constexpr (HAS_LN) {
       const float mu = mean[row], rs = rstd[row];
       f32x4 xh[V];
+      f32x4 gr[V];
       u32x2 dyp[V];   // dy kept packed (bf16) between the two passes: fewer live registers
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int v = 0; v < V; ++v) {
         const int c4 = lane + 64 * v;
         if (c4 < c4n) {
+          if (LN_HOIST_GRES && g_res) gr[v] = *(const f32x4*)(g_res + row * cols + 4 * c4);
           dyp[v] = *(const u32x2*)(dy + row * cols + 4 * c4);
           const f32x4 d = {bf_lo(dyp[v][0]), bf_hi(dyp[v][0]), bf_lo(dyp[v][1]), bf_hi(dyp[v][1])};
           xh[v] = (*(const f32x4*)(x + row * cols + 4 * c4) - mu) * rs;
@@ -126,7 +158,7 @@ __global__ __launch_bounds__(LN_THREADS, (V <= 2 || (V == 3 && !HAS_CS)) ? 4 : (
         if (c4 < c4n) {
           const f32x4 d = {bf_lo(dyp[v][0]), bf_hi(dyp[v][0]), bf_lo(dyp[v][1]), bf_hi(dyp[v][1])};
           dx[v] = (d * g[v] - m1 - xh[v] * m2) * rs;
-          if (g_res) dx[v] += *(const f32x4*)(g_res + row * cols + 4 * c4);
+          if (g_res) dx[v] += LN_HOIST_GRES ? gr[v] : *(const f32x4*)(g_res + row * cols + 4 * c4);
           *(f32x4*)(g_out + row * cols + 4 * c4) = dx[v];
         }
       }
