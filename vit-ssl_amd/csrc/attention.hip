@@ -28,10 +28,38 @@
 #include <stdlib.h>
 #include "common.h"
 
+#ifdef VITSSL_ATTN_STAMPS
+__device__ unsigned long long* g_attn_stamps = nullptr;   // [workgroup][4] x 100 MHz ticks (tools/attn_stamps.py)
+#define ATTN_STAMP(i)                                                                                   \
+  do {                                                                                                  \
+    if (g_attn_stamps && threadIdx.x == 0) g_attn_stamps[(size_t)blockIdx.x * 4 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define ATTN_STAMP(i) \
+  do {                \
+  } while (0)
+#endif
+
 namespace {
 
 constexpr int DH = 64;
 constexpr int ROWB = DH * 2;  // bytes per tile row
+
+// Start-up stagger (developer knob VITSSL_ATTN_STAGGER, in 10 ns ticks; 0 = off).  Every workgroup
+// is load -> compute -> store on equal work, so the chip runs the three phases in lock-step: the load phase
+// of all CUs at once is HBM-bound (~21 GB/s per CU) while HBM idles during the compute phase.  Delaying the
+// FIRST workgroup of every CU by a different fraction of the window spreads the phases; later workgroups
+// inherit the phase of the CU they land on.
+__device__ __forceinline__ void startup_stagger(int first_round_wgs, int window_ticks) {
+  if (window_ticks <= 0 || (int)blockIdx.x >= first_round_wgs) return;
+  if (threadIdx.x < 64) {
+    const unsigned h = (blockIdx.x * 2654435761u) >> 20;               // 12 well-mixed bits
+    const unsigned long long delay = (unsigned long long)window_ticks * h >> 12;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < delay) __builtin_amdgcn_s_sleep(8);
+  }
+  __syncthreads();
+}
 
 __device__ __forceinline__ int tile_off(int row, int ch16) { return row * ROWB + ((ch16 ^ (((row >> 1) & 3) << 1)) << 4); }
 
@@ -169,10 +197,12 @@ __device__ __forceinline__ void softmax_tile(f32x4 (&s)[NKT], float& m_out, floa
 // feeds two MFMAs.
 template <int NS, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                          float* __restrict__ lse, float* __restrict__ probs, int N, int H) {
+                                                          float* __restrict__ lse, float* __restrict__ probs, int N, int H,
+                                                          int stagger_wgs, int stagger_ticks) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int Np = 32 * NS;
   constexpr int NKT = 2 * NS;
+  startup_stagger(stagger_wgs, stagger_ticks);
   char* Kt = smem;
   char* Vt = smem + Np * ROWB;
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
@@ -191,6 +221,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const bf16_t* __re
   // awaited together; the V tile's DMA is issued only then, so it lands underneath the
   // first S = K.Q^T + softmax.  (No ordinary-load result is consumed while a DMA is in
   // flight: hipcc would answer with a full vmcnt(0) drain.)
+  ATTN_STAMP(0);
   bf16x8 qn[2][2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
@@ -201,6 +232,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const bf16_t* __re
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   dma_tile<NW>(Vt, vg, stride, N, Np, wave, lane);
+  ATTN_STAMP(1);
 
   const int iters = (nqp + NW - 1) / NW;   // same trip count for every wave (uniform barriers)
   for (int it = 0; it < iters; ++it) {
@@ -286,7 +318,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const bf16_t* __re
                            pack4((t == 0 ? o0[2 * pr + 1] : o1[2 * pr + 1]) * inv[t]));
       }
     }
+    if (it == 0) ATTN_STAMP(2);
   }
+  ATTN_STAMP(3);
 }
 
 // ------------------------------------------------------------------ backward: dK, dV
@@ -533,10 +567,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 template <int NS, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ outp,
                                                              const bf16_t* __restrict__ dout, const float* __restrict__ lse,
-                                                             bf16_t* __restrict__ dqkv, int N, int H) {
+                                                             bf16_t* __restrict__ dqkv, int N, int H, int stagger_wgs,
+                                                             int stagger_ticks) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int Np = 32 * NS;
-  constexpr int SROW = Np * 2 + 16;     // exchange-image row (bytes); +16 makes the 8-byte column reads conflict-free
+  constexpr int SROW = Np * 2 + 16;
+  startup_stagger(stagger_wgs, stagger_ticks);     // exchange-image row (bytes); +16 makes the 8-byte column reads conflict-free
   char* Qt = smem;
   char* Dt = Qt + Np * ROWB;
   char* Kt = Dt + Np * ROWB;
@@ -555,26 +591,17 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(const bf16_t* _
   const int g = lane >> 4, li = lane & 15;
   const bool has_keys = wave < NS;      // wave-uniform; such a wave has at least one key < N
 
-  // ---- prologue: delta / lse rows, own K / V fragments, then the three LDS tiles
-  for (int row = threadIdx.x >> 1; row < Np; row += 32 * NW) {   // 2 threads per query row
-    const int half = threadIdx.x & 1;
-    float part = 0.f;
-    if (row < N) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const u32x4 ov = *(const u32x4*)(og + (long long)row * ostride + half * 32 + j * 8);
-        const u32x4 dv = *(const u32x4*)(dog + (long long)row * ostride + half * 32 + j * 8);
-#pragma unroll
-        for (int w = 0; w < 4; ++w) part += bf_lo(ov[w]) * bf_lo(dv[w]) + bf_hi(ov[w]) * bf_hi(dv[w]);
-      }
-    }
-    part += __shfl_xor(part, 1, 64);
-    if (half == 0 && row < Np) {
-      // pre-multiplied (log2(e), 1/sqrt(dh)); padded queries: +inf makes p = exp2(x - inf) = 0
-      lse_s[row] = row < N ? lse[((long long)b * H + h) * N + row] * LOG2E : INFINITY;
-      del_s[row] = row < N ? part * SCALE : 0.f;
-    }
-  }
+  // ---- prologue.  Per-CU load bandwidth bounds it (all CUs load at once: ~27 GB/s each), so every
+  // operand is fetched ONCE: Q, dO, K and O arrive as LDS tiles by LDS-DMA (O borrows the dS exchange
+  // area, which is idle until the first step), V fragments come straight from global; the wave's K
+  // fragments and delta = rowsum(dO * O) are then read from the LDS tiles.  (Round 1 also fetched K and dO
+  // a second time from global: 190 KB per workgroup instead of 140, 7.6 us of a 22 us workgroup.)
+  ATTN_STAMP(0);
+  char* Ot = Sx;
+  dma_tile<NW>(Qt, qg, stride, N, Np, wave, lane);
+  dma_tile<NW>(Dt, dog, ostride, N, Np, wave, lane);
+  dma_tile<NW>(Kt, kg, stride, N, Np, wave, lane);
+  dma_tile<NW>(Ot, og, ostride, N, Np, wave, lane);
   bf16x8 kf[2][2], vf[2][2];
   f32x4 kinit[2];
   if (has_keys) {
@@ -584,17 +611,46 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(const bf16_t* _
       const float mi = key < N ? 0.f : -INFINITY;   // masked keys: scores start at -inf -> p = dS = 0
       kinit[kt] = f32x4{mi, mi, mi, mi};
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        kf[kt][kk] = glb_frag(kg, stride, key, kk, N, lane);
-        vf[kt][kk] = glb_frag(vg, stride, key, kk, N, lane);
-      }
+      for (int kk = 0; kk < 2; ++kk) vf[kt][kk] = glb_frag(vg, stride, key, kk, N, lane);
     }
   }
-  dma_tile<NW>(Qt, qg, stride, N, Np, wave, lane);
-  dma_tile<NW>(Dt, dog, ostride, N, Np, wave, lane);
-  dma_tile<NW>(Kt, kg, stride, N, Np, wave, lane);
+  float lrow[(Np + 32 * NW - 1) / (32 * NW)];
+#pragma unroll
+  for (int it = 0; it < (Np + 32 * NW - 1) / (32 * NW); ++it) {
+    const int row = (threadIdx.x >> 1) + it * 32 * NW;
+    lrow[it] = row < N ? lse[((long long)b * H + h) * N + row] : 0.f;
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (has_keys) {
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) kf[kt][kk] = lds_frag(Kt, wave * 32 + kt * 16 + li, kk, lane);
+  }
+#pragma unroll
+  for (int it = 0; it < (Np + 32 * NW - 1) / (32 * NW); ++it) {   // 2 threads per query row
+    const int row = (threadIdx.x >> 1) + it * 32 * NW;
+    const int half = threadIdx.x & 1;
+    float part = 0.f;
+    if (row < N) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32x4 ov = *(const u32x4*)(Ot + tile_off(row, half * 4 + j));
+        const u32x4 dv = *(const u32x4*)(Dt + tile_off(row, half * 4 + j));
+#pragma unroll
+        for (int w = 0; w < 4; ++w) part += bf_lo(ov[w]) * bf_lo(dv[w]) + bf_hi(ov[w]) * bf_hi(dv[w]);
+      }
+    }
+    part += __shfl_xor(part, 1, 64);
+    if (half == 0 && row < Np) {
+      // pre-multiplied (log2(e), 1/sqrt(dh)); padded queries: +inf makes p = exp2(x - inf) = 0
+      lse_s[row] = row < N ? lrow[it] * LOG2E : INFINITY;
+      del_s[row] = row < N ? part * SCALE : 0.f;
+    }
+  }
+  __syncthreads();                                     // delta / lse visible; the O tile may now be overwritten by dS
+  ATTN_STAMP(1);
 
   const f32x4 c4 = {SCALE_LOG2E, SCALE_LOG2E, SCALE_LOG2E, SCALE_LOG2E}, sc4 = {SCALE, SCALE, SCALE, SCALE};
   f32x4 dv[4][2], dk[4][2];
@@ -690,6 +746,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(const bf16_t* _
     __syncthreads();   // every key owner's dS columns of this step are in the image
   }
   dq_tile(Sx + ((NS - 1) & 1) * 32 * SROW, NS - 1);
+  ATTN_STAMP(2);
   if (has_keys) {
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
@@ -705,8 +762,35 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(const bf16_t* _
       }
     }
   }
+#ifdef VITSSL_ATTN_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  ATTN_STAMP(3);
 }
 
+
+int attn_cu_count() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+// stagger window in 10 ns ticks: VITSSL_ATTN_STAGGER="fwd,bwd" (default below; 0 disables)
+int attn_stagger_ticks(int which) {
+  static int v[2] = {-1, -1};
+  if (v[0] < 0) {
+    v[0] = 0;        // forward: two workgroups per CU already overlap each other's loads (stagger measured -2 %)
+    v[1] = 1400;     // fused backward (one workgroup per CU): prologue 6.5 -> 4.9 us per workgroup, launch 269 -> 265 us
+    const char* e = getenv("VITSSL_ATTN_STAGGER");
+    if (e) sscanf(e, "%d,%d", &v[0], &v[1]);
+  }
+  return v[which];
+}
 
 template <typename K>
 int ensure_lds(K kernel, int bytes, bool* done, const char* who) {
@@ -726,7 +810,9 @@ int launch_fwd(const bf16_t* qkv, bf16_t* out, float* lse, float* probs, int B, 
   const int lds = 2 * NS * 32 * ROWB;
   constexpr int NW = NS <= 2 ? 2 : 4;
   if (int rc = ensure_lds(attn_fwd_kernel<NS, NW>, lds, &done, "attn_fwd")) return rc;
-  hipLaunchKernelGGL((attn_fwd_kernel<NS, NW>), dim3(B * H), dim3(64 * NW), lds, s, qkv, out, lse, probs, N, H);
+  const int per_cu = lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3);
+  hipLaunchKernelGGL((attn_fwd_kernel<NS, NW>), dim3(B * H), dim3(64 * NW), lds, s, qkv, out, lse, probs, N, H,
+                     attn_cu_count() * per_cu, B * H > 2 * attn_cu_count() * per_cu ? attn_stagger_ticks(0) : 0);
   VS_CHECK_LAUNCH("attn_fwd");
   return VITSSL_OK;
 }
@@ -749,7 +835,9 @@ int launch_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const f
     constexpr int NW = NS <= 2 ? 2 : (NS <= 4 ? 4 : 8);
     const int lds_f = 3 * NS * 32 * ROWB + 2 * 32 * (NS * 64 + 16) + 2 * NS * 32 * 4;
     if (int rc = ensure_lds(attn_bwd_fused_kernel<NS, NW>, lds_f, &done_f, "attn_bwd_fused")) return rc;
-    hipLaunchKernelGGL((attn_bwd_fused_kernel<NS, NW>), dim3(B * H), dim3(64 * NW), lds_f, s, qkv, out, dout, lse, dqkv, N, H);
+    const int per_cu = lds_f > 80 * 1024 ? 1 : 2;
+    hipLaunchKernelGGL((attn_bwd_fused_kernel<NS, NW>), dim3(B * H), dim3(64 * NW), lds_f, s, qkv, out, dout, lse, dqkv, N, H,
+                       attn_cu_count() * per_cu, B * H > 2 * attn_cu_count() * per_cu ? attn_stagger_ticks(1) : 0);
     VS_CHECK_LAUNCH("attn_bwd_fused");
     return VITSSL_OK;
   }
@@ -785,6 +873,13 @@ int check_attn_shape(const char* who, int B, int N, int H, int dh) {
 }
 
 }  // namespace
+
+#ifdef VITSSL_ATTN_STAMPS
+extern "C" int vitssl_debug_attn_stamps(void* buf) {
+  unsigned long long* p = (unsigned long long*)buf;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamps), &p, sizeof(p));
+}
+#endif
 
 extern "C" int vitssl_attn_fwd(const void* qkv, void* out, float* lse, float* probs, int B, int N, int H, int dh,
                                void* stream) {
