@@ -49,6 +49,11 @@
 #ifndef NT_BF16_AUX
 #define NT_BF16_AUX 0
 #endif
+// g' = keep*scale*gelu'(u), the second image of the FC1 epilogue, is read again only in backward: its stores
+// are non-temporal (2) so that `a`, which FC2 reads next, keeps its lines (in-step A/B: -0.25 ms per ViT-B step; sc1 = 16: slower)
+#ifndef NT_GPRIME_AUX
+#define NT_GPRIME_AUX 2
+#endif
 // 1: every epilogue load / store instruction touches 8 rows x 128 bytes (whole cache lines; lanes
 // r and r^8 of a 16-lane row exchange halves with a DPP rotate) instead of 16 rows x 64 bytes
 #ifndef NT_ROWS128
@@ -231,7 +236,8 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
   };
   // one row tile of a bf16 image: w[jp][h]
   constexpr int BF16_AUX = NT_STORE_AUX != 0 ? NT_STORE_AUX : NT_BF16_AUX;
-  auto store_bf16_row = [&](__amdgpu_buffer_rsrc_t rs, int i, const u32x2 (&w)[2][2]) {
+  auto store_bf16_row = [&](__amdgpu_buffer_rsrc_t rs, int i, const u32x2 (&w)[2][2], auto aux_c) {
+    constexpr int AUXV = decltype(aux_c)::value;
     if (NT_ABLATE == 1) {
       asm volatile("" ::"v"(w[0][0]), "v"(w[0][1]), "v"(w[1][0]), "v"(w[1][1]));
       return;
@@ -241,18 +247,18 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
       if (NT_ROWS128) {
         u32x4 s1, s2;
         to_lines(a, b, s1, s2);
-        __builtin_amdgcn_raw_buffer_store_b128(s1, rs, off_bf16_line(i, 0), 0, BF16_AUX);
-        __builtin_amdgcn_raw_buffer_store_b128(s2, rs, off_bf16_line(i, 1), 0, BF16_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(s1, rs, off_bf16_line(i, 0), 0, AUXV);
+        __builtin_amdgcn_raw_buffer_store_b128(s2, rs, off_bf16_line(i, 1), 0, AUXV);
       } else {
-        __builtin_amdgcn_raw_buffer_store_b128(a, rs, off_bf16_wide(i, 0), 0, BF16_AUX);
-        __builtin_amdgcn_raw_buffer_store_b128(b, rs, off_bf16_wide(i, 1), 0, BF16_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(a, rs, off_bf16_wide(i, 0), 0, AUXV);
+        __builtin_amdgcn_raw_buffer_store_b128(b, rs, off_bf16_wide(i, 1), 0, AUXV);
       }
     } else {
 #pragma unroll
       for (int jp = 0; jp < 2; ++jp) {
         const int na = n0 + wn * 64 + (2 * jp) * 16 + 4 * g4;
-        __builtin_amdgcn_raw_buffer_store_b64(w[jp][0], rs, off_elem(i, na, 2u), 0, BF16_AUX);
-        __builtin_amdgcn_raw_buffer_store_b64(w[jp][1], rs, off_elem(i, na + 16, 2u), 0, BF16_AUX);
+        __builtin_amdgcn_raw_buffer_store_b64(w[jp][0], rs, off_elem(i, na, 2u), 0, AUXV);
+        __builtin_amdgcn_raw_buffer_store_b64(w[jp][1], rs, off_elem(i, na + 16, 2u), 0, AUXV);
       }
     }
   };
@@ -451,9 +457,9 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
       }
       // the row's 128 bytes of every bf16 image leave in back-to-back instructions
       if constexpr (EPI == VITSSL_EPI_BF16 || EPI == VITSSL_EPI_GELU || EPI == VITSSL_EPI_DGELU) {
-        store_bf16_row(rsOut0, i, out_a);
+        store_bf16_row(rsOut0, i, out_a, IC<(EPI == VITSSL_EPI_GELU && NT_STORE_AUX == 0) ? NT_GPRIME_AUX : BF16_AUX>{});
       }
-      if constexpr (EPI == VITSSL_EPI_GELU) store_bf16_row(rsOut1, i, out_b);
+      if constexpr (EPI == VITSSL_EPI_GELU) store_bf16_row(rsOut1, i, out_b, IC<BF16_AUX>{});
     }
   }
 
@@ -1005,7 +1011,9 @@ int launch_pp(NtParams p, hipStream_t s) {
   static float stagger_scale = -1.f;
   if (stagger_scale < 0.f) {
     const char* e = getenv("VITSSL_NT_STAGGER");       // developer knob: scale of the window, 0 = off
-    stagger_scale = e ? (float)atof(e) : 1.0f;
+    // default OFF: time-neutral (the epilogue is bound inside each CU, not by a chip-wide burst) and it costs L2
+    // sharing -- workgroups on the same A row panel no longer run in step, FETCH_SIZE of the N = 768 launches x2
+    stagger_scale = e ? (float)atof(e) : 0.0f;
   }
   const float epi_us = EPI == VITSSL_EPI_BF16 ? 2.f : EPI == VITSSL_EPI_GELU ? 7.f : EPI == VITSSL_EPI_DGELU ? 5.f
                        : EPI == VITSSL_EPI_RESID ? 8.f : 4.f;
