@@ -171,6 +171,11 @@ typedef __attribute__((ext_vector_type(8))) short tn_s16x8;
 #ifndef TN_ABLATE
 #define TN_ABLATE 0
 #endif
+// phases (barrier pairs) per K-tile: 4 = 16 MFMAs per phase, 2 = 32 MFMAs per phase (half the barriers, one
+// K-tile of prefetch distance instead of 1.5)
+#ifndef TN_PHASES
+#define TN_PHASES 2
+#endif
 
 
 template <int N>
@@ -334,6 +339,74 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_pp_kernel(TnParams p) {
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
 
+#if TN_PHASES == 2
+  s16x4 ta2[8][2];
+  bf16x8 fa2[8];
+  auto read_a8 = [&](int bufoff, auto ks_c) {
+    constexpr int ks = decltype(ks_c)::value;
+#pragma unroll
+    for (int ii = 0; ii < 8; ++ii) {
+      const unsigned a = fragA[ii] + (unsigned)bufoff;
+      tn_ds_tr<ks * 16384>(ta2[ii][0], a);
+      tn_ds_tr<ks * 16384 + 2048>(ta2[ii][1], a);
+    }
+  };
+  auto landed8 = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const tn_s16x8 v = {tb[j][0][0], tb[j][0][1], tb[j][0][2], tb[j][0][3], tb[j][1][0], tb[j][1][1], tb[j][1][2], tb[j][1][3]};
+      fb[j] = __builtin_bit_cast(bf16x8, v);
+    }
+#pragma unroll
+    for (int ii = 0; ii < 8; ++ii) {
+      const tn_s16x8 v = {ta2[ii][0][0], ta2[ii][0][1], ta2[ii][0][2], ta2[ii][0][3], ta2[ii][1][0], ta2[ii][1][1], ta2[ii][1][2], ta2[ii][1][3]};
+      fa2[ii] = __builtin_bit_cast(bf16x8, v);
+    }
+  };
+  auto mma32 = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ii = 0; ii < 8; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa2[ii], acc[ii][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  if (nk > 0) {
+    stage_b(0, 0, I0{});
+    stage_a(0, 0, I0{});
+    stage_b(0, 0, I1{});
+    stage_a(0, 0, I1{});
+    tn_wait_vmcnt<4>();                                // the ks-0 halves of K-tile 0 have landed
+    tn_section();
+    if (w1 == 1) tn_section();                         // waves 4-7 run one barrier behind waves 0-3
+    int buf = 0;
+    for (int t = 0; t < nk; ++t) {
+      const int cur = buf * BUF;
+      // phase A: ks 0 (all 32 MFMAs); the ks-0 halves of K-tile t+1 go into the other buffer
+      read_b(cur, I0{});
+      read_a8(cur, I0{});
+      stage_b(t + 1, buf ^ 1, I0{});
+      stage_a(t + 1, buf ^ 1, I0{});
+      tn_wait_vmcnt<4>();
+      tn_section();
+      landed8();
+      mma32();
+      tn_section();
+      // phase B: ks 1
+      read_b(cur, I1{});
+      read_a8(cur, I1{});
+      stage_b(t + 1, buf ^ 1, I1{});
+      stage_a(t + 1, buf ^ 1, I1{});
+      tn_wait_vmcnt<4>();
+      tn_section();
+      landed8();
+      mma32();
+      if (!(t + 1 == nk && w1 == 1)) tn_section();
+      buf ^= 1;
+    }
+#else
   if (nk > 0) {
     stage_b(0, 0, I0{});
     stage_a(0, 0, I0{});
@@ -381,6 +454,7 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_pp_kernel(TnParams p) {
       if (!(t + 1 == nk && w1 == 1)) tn_section();
       buf ^= 1;
     }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing zero-fill DMA retired before the LDS is released
   }
 
