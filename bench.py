@@ -273,7 +273,7 @@ def main():
         name, (fl, ms, cnt) = dom
         ach = fl / (ms * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic_per_launch(name) if args.model == "vit_b" and args.batch == 256 else (None, None)
-        roofline = {"kernel": name + "_kernel", "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
+        roofline = {"kernel": {"gemm_nt": "gemm_nt_pp_kernel", "gemm_tn": "gemm_tn_pp_kernel"}.get(name, name + "_kernel"), "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                     "traffic": None if traffic is None else round(traffic), "traffic_unit": "bytes/launch (HBM, PMC)",
                     "traffic_source": traffic_src,

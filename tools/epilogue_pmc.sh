@@ -43,10 +43,11 @@ for d in sorted(glob.glob(out + "/e*")):
     hbm = (2 * row.get("FETCH_SIZE", 0) + row.get("WRITE_SIZE", 0)) * 1024
     res[f"epi{epi}_N{N}_K{K}"] = dict(us=us, tflops=None if not us else round(2.0 * M * N * K / us / 1e6, 1), alg_bytes=alg,
                                       hbm_bytes_pmc=round(hbm), traffic_ratio=round(hbm / alg, 3), counters=row,
-                                      mfma_busy_frac=None if "SQ_BUSY_CYCLES" not in row else round(row.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(row["SQ_BUSY_CYCLES"], 1) / 4, 3),
+                                      mfma_busy_frac=None if not us else round(row.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024 / (us * 2400.0), 3),
                                       wait_any_frac=None if "SQ_WAVE_CYCLES" not in row else round(row.get("SQ_WAIT_ANY", 0) / max(row["SQ_WAVE_CYCLES"], 1), 3))
 res["note"] = ("rocprofv3 passes of tools/one_gemm.py (6 launches, first two dropped); FETCH_SIZE doubled (gfx950 wide reads, "
-               "MI355X_MICROARCH.md), unit KB; SQ_* summed over the chip; us = median kernel duration of the --kernel-trace pass")
+               "MI355X_MICROARCH.md), unit KB; SQ_* summed over the chip; us = median kernel duration of the --kernel-trace pass; "
+               "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES (16 per 16x16x32 MFMA, summed over SIMDs) / 1024 SIMDs / (us x 2.4 GHz peak clock)")
 json.dump(res, open(dst, "w"), indent=1)
 for k, v in res.items():
     if k != "note":
