@@ -117,6 +117,37 @@ typedef struct {
 
 int vitssl_gemm_bf16_nt(const vitssl_gemm_t* g, void* stream);
 
+/* ---- fp8 (OCP e4m3fn) operand path of the FORWARD Linear layers: BASELINE.json configs[4],
+ * "ViT-L/16 SimMIM, fp8 MFMA weight path" (the same nn.Linear call sites as above:
+ * vit_core/attention.py:54-58,105; feed_forward.py:14-15,26-28).  Same contraction, epilogues and
+ * output types as vitssl_gemm_bf16_nt, but A [M,K] and B [N,K] are e4m3 bytes, K % 128 == 0, and the
+ * MFMA is v_mfma_f32_16x16x128_f8f6f4 (fp32 accumulate).  Epilogues BF16 / F32 / GELU / RESID; the
+ * backward GEMMs keep bf16 operands. */
+typedef struct {
+  const float* alpha; /* device scalar: acc is multiplied by *alpha before the epilogue (product of the
+                         operands' dequantisation scales; vitssl_fp8_quantize_weights writes it), or NULL = 1 */
+  void* out_fp8;      /* EPI_GELU only: e4m3 [M,N] image of out1 (the A operand of the next fp8 GEMM), or NULL */
+} vitssl_fp8_gemm_t;
+int vitssl_gemm_fp8_nt(const vitssl_gemm_t* g, const vitssl_fp8_gemm_t* q, void* stream);
+
+/* y_fp8[n] = e4m3(clamp(x, -448, 448)), round to nearest even (activations are quantised at unit scale) */
+int vitssl_quantize_fp8(const void* x_bf16, void* y_fp8, int64_t n, void* stream);
+/* LayerNorm forward that also emits the e4m3 image of its output (operand of the next fp8 GEMM);
+ * y_bf16 is still written: the weight-gradient GEMM of the backward pass reads it. */
+int vitssl_layernorm_fwd_fp8(const float* x, const float* gamma, const float* beta, void* y_bf16, void* y_fp8,
+                             float* mean, float* rstd, int64_t rows, int cols, float eps, void* stream);
+/* Per-step fp8 refresh of a table of weights in one call (three launches): per tensor j,
+ * amax_j = max|src|, k_j = floor(log2(448 / amax_j)) (0 when amax_j = 0; a power-of-two scale is exact),
+ * dst_fp8 = e4m3(src * 2^k_j), alpha[j] = 2^-k_j.  `jobs`, `chunk_start`, `amax_ws` [njobs] and `alpha`
+ * [njobs] live in DEVICE memory; chunk_start[njobs + 1] is the exclusive prefix sum of ceil(n / 4096). */
+typedef struct {
+  const float* src; /* f32 [n] */
+  void* dst_fp8;    /* e4m3 [n] */
+  int64_t n;
+} vitssl_fp8_weight_job_t;
+int vitssl_fp8_quantize_weights(const vitssl_fp8_weight_job_t* jobs, const int* chunk_start, int njobs, int total_chunks,
+                                float* amax_ws, float* alpha, void* stream);
+
 /* Weight gradient: C[N1,N2] (fp32) += A[M,N1]^T . B[M,N2]  (contraction over rows).
  * Split over M across workgroups.  With a workspace of at least
  * vitssl_gemm_tn_workspace_floats(M,N1,N2) floats the partial tiles are combined through

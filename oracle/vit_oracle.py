@@ -14,6 +14,14 @@ Two modes:
     attention probabilities/context, MLP hidden).  Used by the GPU parity
     tests to separate "kernel bug" from "bf16 rounding" with a tight tolerance.
 
+  * ``emu="fp8"`` : as "bf16", but the four Linear layers of every encoder block
+    run their FORWARD product on OCP e4m3fn operands (BASELINE configs[4], "fp8
+    weight path"): activations quantised at unit scale (saturating at +-448),
+    weights per tensor with the power-of-two scale 2^floor(log2(448 / max|w|)),
+    fp32 accumulation; their backward products use the bf16 operands, as the HIP
+    path does.  The reference has no fp8 code: this mode restates the HIP design,
+    and is tied to the reference only through its fp32 / bf16 siblings.
+
 Pinned against fixtures generated from the reference (tests/golden).
 """
 from __future__ import annotations
@@ -46,9 +54,59 @@ class _RoundBF16(torch.autograd.Function):
 def rnd(x: Tensor, emu: Optional[str]) -> Tensor:
     if emu is None:
         return x
-    if emu == "bf16":
+    if emu in ("bf16", "fp8"):
         return _RoundBF16.apply(x)
     raise ValueError(emu)
+
+
+E4M3_MAX = 448.0
+
+
+def q8(x: Tensor) -> Tensor:
+    """fp32 -> OCP e4m3fn -> fp32: round to nearest even, saturating at +-448."""
+    return x.clamp(-E4M3_MAX, E4M3_MAX).to(torch.float8_e4m3fn).to(torch.float32)
+
+
+def fp8_scale_exp(amax: float) -> int:
+    """k = floor(log2(448 / amax)) computed on the binary representation (no log2 rounding): amax = fr 2^e with
+    fr in [0.5, 1), 448 = 0.875 2^9; k = 0 for amax = 0."""
+    if not (amax > 0.0) or not math.isfinite(amax):
+        return 0
+    fr, e = math.frexp(float(torch.tensor(amax, dtype=torch.float32)))
+    k = 9 - e - (0 if fr <= 0.875 else 1)
+    return max(-120, min(120, k))
+
+
+class _LinearFP8(torch.autograd.Function):
+    """y = (q8(x) . q8(w 2^k)^T) 2^-k in the forward; the backward products take bf16(x) and bf16(w)."""
+
+    @staticmethod
+    def forward(ctx, x32, w, k, via_bf16):
+        xb = x32.to(torch.bfloat16).to(torch.float32)
+        wb = w.to(torch.bfloat16).to(torch.float32)
+        x8 = q8(xb if via_bf16 else x32)
+        w8 = q8(w * (2.0 ** k))
+        ctx.save_for_backward(xb, wb)
+        return (x8 @ w8.t()) * (2.0 ** -k)
+
+    @staticmethod
+    def backward(ctx, g):
+        xb, wb = ctx.saved_tensors
+        gx = g @ wb
+        gw = g.reshape(-1, g.shape[-1]).t() @ xb.reshape(-1, xb.shape[-1])
+        return gx, gw, None, None
+
+
+def linear_fp8(x32: Tensor, w: Tensor, b: Optional[Tensor], k: Optional[int] = None, via_bf16: bool = False) -> Tensor:
+    """Block Linear on e4m3 operands.  `x32` is the fp32 value the HIP producer holds when it writes its bf16 and
+    e4m3 images (via_bf16: the e4m3 image is made from the bf16 one).  `k`: scale exponent of the weight tensor
+    (default: from this tensor's own max; the fused QKV weight shares one)."""
+    if k is None:
+        k = fp8_scale_exp(float(w.detach().abs().max()))
+    y = _LinearFP8.apply(x32, w, k, via_bf16)
+    if b is not None:
+        y = y + b
+    return y
 
 
 # --------------------------------------------------------------------------
@@ -108,25 +166,41 @@ def mha(x: Tensor, sd: SD, pre: str, num_heads: int, emu=None, return_attn=False
     Three bias-free projections, head split, SDPA, merge, bias-free final_linear."""
     B, N, D = x.shape
     dh = D // num_heads
-    q = rnd(linear(x, sd[pre + "w_query.weight"], None, emu), emu)
-    k = rnd(linear(x, sd[pre + "w_key.weight"], None, emu), emu)
-    v = rnd(linear(x, sd[pre + "w_value.weight"], None, emu), emu)
+    if emu == "fp8":
+        # x is the un-rounded LayerNorm output; the HIP path multiplies by ONE fused [3D, D] weight image
+        kq = fp8_scale_exp(max(float(sd[pre + n].detach().abs().max()) for n in ("w_query.weight", "w_key.weight", "w_value.weight")))
+        q = rnd(linear_fp8(x, sd[pre + "w_query.weight"], None, kq), emu)
+        k = rnd(linear_fp8(x, sd[pre + "w_key.weight"], None, kq), emu)
+        v = rnd(linear_fp8(x, sd[pre + "w_value.weight"], None, kq), emu)
+    else:
+        q = rnd(linear(x, sd[pre + "w_query.weight"], None, emu), emu)
+        k = rnd(linear(x, sd[pre + "w_key.weight"], None, emu), emu)
+        v = rnd(linear(x, sd[pre + "w_value.weight"], None, emu), emu)
     q = q.view(B, N, num_heads, dh).transpose(1, 2)
     k = k.view(B, N, num_heads, dh).transpose(1, 2)
     v = v.view(B, N, num_heads, dh).transpose(1, 2)
-    o, p = sdpa(q, k, v, emu)
-    o = rnd(o, emu).transpose(1, 2).reshape(B, N, D)
-    out = linear(o, sd[pre + "final_linear.weight"], None, emu)
+    o, p = sdpa(q, k, v, "bf16" if emu == "fp8" else emu)
+    if emu == "fp8":
+        # the attention kernel stores bf16; its e4m3 image is made from that store
+        out = linear_fp8(o.transpose(1, 2).reshape(B, N, D), sd[pre + "final_linear.weight"], None, via_bf16=True)
+    else:
+        o = rnd(o, emu).transpose(1, 2).reshape(B, N, D)
+        out = linear(o, sd[pre + "final_linear.weight"], None, emu)
     return (out, p) if return_attn else (out, None)
 
 
 def feed_forward(x: Tensor, sd: SD, pre: str, emu=None, keep_inner: Optional[Tensor] = None,
                  p_drop: float = 0.0) -> Tensor:
     """FeedForwardBlock.forward (vit_core/feed_forward.py:26-28)."""
-    u = rnd(linear(x, sd[pre + "linear_in.weight"], sd[pre + "linear_in.bias"], emu), emu)
+    if emu == "fp8":
+        u = rnd(linear_fp8(x, sd[pre + "linear_in.weight"], sd[pre + "linear_in.bias"]), emu)
+    else:
+        u = rnd(linear(x, sd[pre + "linear_in.weight"], sd[pre + "linear_in.bias"], emu), emu)
     a = gelu_erf(u)
     if keep_inner is not None:
         a = a * keep_inner / (1.0 - p_drop)
+    if emu == "fp8":
+        return linear_fp8(a, sd[pre + "linear_out.weight"], sd[pre + "linear_out.bias"])
     a = rnd(a, emu)
     return linear(a, sd[pre + "linear_out.weight"], sd[pre + "linear_out.bias"], emu)
 
@@ -139,12 +213,14 @@ def encoder_block(x: Tensor, sd: SD, pre: str, num_heads: int, emu=None,
     ``keep`` = optional (keep1, keep_inner, keep2) 0/1 masks for the three
     dropout sites (drop1, FFN inner, drop2); survivors scaled by 1/(1-p)."""
     sc = 1.0 / (1.0 - p_drop) if keep is not None else 1.0
-    h = rnd(layer_norm(x, sd[pre + "layer_norm1.weight"], sd[pre + "layer_norm1.bias"]), emu)
+    # (fp8: the Linear layers take the un-rounded LayerNorm output and make both operand images themselves)
+    ln_emu = None if emu == "fp8" else emu
+    h = rnd(layer_norm(x, sd[pre + "layer_norm1.weight"], sd[pre + "layer_norm1.bias"]), ln_emu)
     a, probs = mha(h, sd, pre + "self_attention.", num_heads, emu, return_attn)
     if keep is not None:
         a = a * keep[0] * sc
     x = x + a
-    h = rnd(layer_norm(x, sd[pre + "layer_norm2.weight"], sd[pre + "layer_norm2.bias"]), emu)
+    h = rnd(layer_norm(x, sd[pre + "layer_norm2.weight"], sd[pre + "layer_norm2.bias"]), ln_emu)
     f = feed_forward(h, sd, pre + "feed_forward.", emu,
                      keep_inner=None if keep is None else keep[1], p_drop=p_drop)
     if keep is not None:

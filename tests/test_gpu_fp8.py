@@ -1,0 +1,252 @@
+"""fp8 (OCP e4m3fn) operand path of the forward Linear layers -- BASELINE.json configs[4].
+
+Integer / byte work is bit-exact (the quantisers against torch's own float8_e4m3fn conversion, the per-tensor
+power-of-two weight scales against the oracle's exponent rule); the GEMM is compared with an fp32 product of the
+SAME e4m3 operands (products of e4m3 values are exact in fp32, so only the summation order differs: 2e-5);
+blocks and models are compared with the oracle's emu="fp8" mode at the bf16 path's tolerances, and with the pure
+fp32 oracle at the tolerance e4m3's 3 mantissa bits allow (stated per assert)."""
+import pytest
+import torch
+
+from _util import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+FP8 = torch.float8_e4m3fn
+
+
+def _q8_torch(x32):
+    return x32.clamp(-448.0, 448.0).to(FP8)
+
+
+def _f32(t8):
+    """e4m3 -> fp32 on the host (exact), back on the tensor's device"""
+    return t8.cpu().float().to(t8.device)
+
+
+@pytest.fixture
+def fp8_operands():
+    from vitssl_hip import engine
+    engine.set_linear_operands("fp8")
+    yield
+    engine.set_linear_operands("bf16")
+
+
+def test_quantize_fp8_bit_exact():
+    from vitssl_hip import ops
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1 << 16, generator=g) * torch.exp2(torch.randint(-12, 10, (1 << 16,), generator=g).float())
+    edge = torch.tensor([0.0, -0.0, 448.0, -448.0, 449.0, 464.0, 480.0, 1e4, -1e4, 2.0 ** -9, 2.0 ** -10, 1.5 * 2.0 ** -10,
+                         3.0 * 2.0 ** -10, 2.0 ** -6, 0.0029, 1.0625, 1.125, 1.1875, 17.9, -3.3, 2.0 ** -20])
+    x = torch.cat([edge, x])[: (1 << 16) + 5].to(torch.bfloat16)      # odd length: exercises the tail
+    xd = x.to(DEV)
+    y = torch.empty(x.shape, dtype=FP8, device=DEV)
+    ops.quantize_fp8(xd, y)
+    want = _q8_torch(x.float())
+    assert torch.equal(y.cpu().view(torch.uint8), want.view(torch.uint8))
+
+
+def test_fp8_weight_images_bit_exact():
+    from oracle import vit_oracle as O
+    from vitssl_hip import ops
+    g = torch.Generator().manual_seed(1)
+    shapes = [(384, 128), (128, 128), (512, 128), (128, 512), (5, 7)]
+    scales = [0.02, 3.0, 448.0 / 4.0, 1e-6, 0.5]
+    srcs = [(torch.randn(*s, generator=g) * sc) for s, sc in zip(shapes, scales)]
+    srcs[2][0, 0] = 448.0            # amax exactly on the 0.875 boundary of the exponent rule
+    srcs.append(torch.zeros(64, 64))  # all-zero tensor: scale exponent 0
+    dev = [s.to(DEV) for s in srcs]
+    dst = [torch.empty(s.shape, dtype=FP8, device=DEV) for s in srcs]
+    plan = ops.Fp8WeightPlan()
+    plan.run(list(zip(dev, dst)))
+    plan.run(list(zip(dev, dst)))     # cached job table
+    alpha = plan.alpha.cpu()
+    for i, s in enumerate(srcs):
+        k = O.fp8_scale_exp(float(s.abs().max()))
+        assert float(alpha[i]) == 2.0 ** -k, (i, float(alpha[i]), k)
+        want = _q8_torch(s * (2.0 ** k))
+        assert torch.equal(dst[i].cpu().view(torch.uint8), want.view(torch.uint8)), i
+        assert float(want.float().abs().max()) <= 448.0 and (float(s.abs().max()) == 0 or float(want.float().abs().max()) > 224.0 * 0.9)
+
+
+@pytest.mark.parametrize("cols", [128, 384, 768, 1024])
+def test_layernorm_fwd_fp8_images(cols):
+    from vitssl_hip import ops
+    torch.manual_seed(cols)
+    rows = 301
+    x = (torch.randn(rows, cols) * 3 + 0.5).to(DEV)
+    gamma, beta = (1 + 0.2 * torch.randn(cols)).to(DEV), (0.1 * torch.randn(cols)).to(DEV)
+    y = torch.empty(rows, cols, dtype=torch.bfloat16, device=DEV)
+    y2 = torch.empty_like(y)
+    y8 = torch.empty(rows, cols, dtype=FP8, device=DEV)
+    m, r = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    ops.layernorm_fwd(x, gamma, beta, y2, m, r)
+    ops.layernorm_fwd_fp8(x, gamma, beta, y, y8, m, r)
+    assert torch.equal(y, y2)                                          # the bf16 image is the bf16 kernel's
+    ref = torch.nn.functional.layer_norm(x, (cols,), gamma, beta)
+    want = _q8_torch(ref.cpu())
+    same = (y8.cpu().view(torch.uint8) == want.view(torch.uint8)).float().mean()
+    assert float(same) > 0.995                                         # fp32 ulp differences flip a rounding now and then
+    assert rel_l2(_f32(y8), ref) < 4e-2                              # e4m3: relative step 2^-3, rms error ~ 2^-3 / sqrt(12)
+
+
+SHAPES = [(300, 128, 128), (1000, 384, 256), (517, 260, 1024), (4096, 512, 512)]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_gemm_fp8_epilogues(M, N, K):
+    from vitssl_hip import _lib as L, ops
+    torch.manual_seed(M + N + K)
+    A = _q8_torch(torch.randn(M, K) * 2).to(DEV)
+    Bw = _q8_torch(torch.randn(N, K) * 100).to(DEV)
+    alpha = torch.tensor([2.0 ** -7], device=DEV)
+    bias = torch.randn(N, device=DEV)
+    ref = (_f32(A) @ _f32(Bw).t()) * alpha + bias
+    out32 = torch.empty(M, N, device=DEV)
+    ops.gemm_fp8_nt(A, Bw, out32, L.EPI_F32, alpha=alpha, bias=bias)
+    assert rel_l2(out32, ref) < 2e-5
+    out16 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_fp8_nt(A, Bw, out16, L.EPI_BF16, alpha=alpha, bias=bias)
+    assert rel_l2(out16, ref) < 4e-3 and torch.equal(out16, out32.to(torch.bfloat16))
+    # no alpha / no bias
+    ops.gemm_fp8_nt(A, Bw, out32, L.EPI_F32)
+    assert rel_l2(out32, _f32(A) @ _f32(Bw).t()) < 2e-5
+    # residual + dropout: the mask stream is the bf16 kernel's (same element index)
+    res = torch.randn(M, N, device=DEV)
+    drop = ops.make_dropout(0.25, 11, 3)
+    keep = ops.dropout_mask(M, N, drop, DEV).float()
+    ops.gemm_fp8_nt(A, Bw, out32, L.EPI_RESID, alpha=alpha, bias=bias, aux=res, drop=drop)
+    assert rel_l2(out32, res + ref * keep / 0.75) < 2e-5
+    # GELU: g' image, bf16 a, e4m3 a
+    u = ref.to(torch.bfloat16).float()
+    a_ref = torch.nn.functional.gelu(u) * keep / 0.75
+    gp = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    a16 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    a8 = torch.empty(M, N, dtype=FP8, device=DEV)
+    ops.gemm_fp8_nt(A, Bw, gp, L.EPI_GELU, alpha=alpha, bias=bias, out1=a16, out_fp8=a8, drop=drop)
+    assert rel_l2(a16, a_ref) < 4e-3
+    assert rel_l2(_f32(a8), a_ref) < 4e-2
+    same = (a8.cpu().view(torch.uint8) == _q8_torch(a_ref.cpu()).view(torch.uint8)).float().mean()
+    assert float(same) > 0.99
+    cdf = 0.5 * (1 + torch.erf(u / 2 ** 0.5))
+    gp_ref = (cdf + u * torch.exp(-0.5 * u * u) / (2 * torch.pi) ** 0.5) * keep / 0.75
+    assert rel_l2(gp, gp_ref) < 4e-3
+    a16b = torch.empty_like(a16)
+    ops.gemm_fp8_nt(A, Bw, gp, L.EPI_GELU, alpha=alpha, bias=bias, out1=a16b, drop=drop)   # without the e4m3 image
+    assert torch.equal(a16, a16b)
+
+
+def test_gemm_fp8_identity_layout():
+    """A = I against an asymmetric B: catches a row/column swap or a k-permutation that differs between operands."""
+    from vitssl_hip import _lib as L, ops
+    K = 256
+    A = torch.eye(K)[:, :K].to(FP8).to(DEV)
+    Bm = torch.zeros(384, K)
+    for n in range(384):
+        for j in range(4):
+            Bm[n, (7 * n + 13 * j) % K] = float((n + 3 * j) % 15 + 1)
+    out = torch.empty(K, 384, device=DEV)
+    ops.gemm_fp8_nt(A, Bm.to(FP8).to(DEV), out, L.EPI_F32)
+    assert torch.equal(out.cpu(), Bm.t().contiguous())
+
+
+def test_gemm_fp8_rejects_bad_arguments():
+    from vitssl_hip import _lib as L, ops
+    A = torch.zeros(64, 192, dtype=FP8, device=DEV)
+    Bw = torch.zeros(64, 192, dtype=FP8, device=DEV)
+    with pytest.raises(L.VitsslError):
+        ops.gemm_fp8_nt(A, Bw, torch.empty(64, 64, device=DEV), L.EPI_F32)               # K % 128
+    A = torch.zeros(64, 128, dtype=FP8, device=DEV)
+    Bw = torch.zeros(64, 128, dtype=FP8, device=DEV)
+    with pytest.raises(L.VitsslError):
+        ops.gemm_fp8_nt(A, Bw, torch.empty(64, 64, dtype=torch.bfloat16, device=DEV), L.EPI_DGELU)
+    with pytest.raises(L.VitsslError):
+        ops.gemm_fp8_nt(A.to(torch.bfloat16), Bw, torch.empty(64, 64, device=DEV), L.EPI_F32)
+
+
+def test_encoder_block_fp8_matches_oracle(fp8_operands):
+    from vit_core import EncoderBlock
+    from oracle import vit_oracle as O
+    torch.manual_seed(3)
+    blk = EncoderBlock(d_model=128, num_heads=2, mlp_dim=256, dropout=0.0)
+    sd = {k: v.detach().clone() for k, v in blk.state_dict().items()}
+    blk = blk.to(DEV).train()
+    x = torch.randn(3, 20, 128)
+    xd = x.to(DEV).requires_grad_(True)
+    y, _ = blk(xd)
+    y.square().mean().backward()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    ry, _ = O.encoder_block(xr, leaves, "", 2, emu="fp8")
+    ry.square().mean().backward()
+    assert rel_l2(y, ry) < 1e-2                      # same quantisation points: the bf16 path's tolerance
+    assert rel_l2(xd.grad, xr.grad) < 5e-2
+    for k, p in blk.named_parameters():
+        assert rel_l2(p.grad, leaves[k].grad) < 5e-2, (k, rel_l2(p.grad, leaves[k].grad))
+    fy, _ = O.encoder_block(x, sd, "", 2)
+    assert 1e-3 < rel_l2(y, fy) < 5e-2               # and against pure fp32: e4m3 operands cost ~1.5 % here (bf16: 0.1 %)
+
+
+def test_simmim_fp8_matches_oracle_and_trains(fp8_operands):
+    from vit_core.ssl.simmim import SimMIMViT
+    from vit_core.ssl.simmim.masking import draw_mask
+    from vitssl_hip.optim import FusedAdamW
+    from oracle import vit_oracle as O
+    torch.manual_seed(11)
+    model = SimMIMViT(num_blocks=2, input_shape=(3, 64, 64), embed_dim=128, patch_size=16, num_heads=2, mlp_dim=256,
+                      dropout=0.0, mask_ratio=0.6)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV).train()
+    x = torch.rand(4, 3, 64, 64, generator=torch.Generator().manual_seed(5))
+    torch.manual_seed(9)
+    pred, tgt = model(x.to(DEV))
+    loss = torch.nn.functional.l1_loss(pred, tgt)
+    loss.backward()
+    torch.manual_seed(9)
+    mask = draw_mask(4, 16, 0.6)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    pe, te = O.simmim_forward(leaves, x, mask, 16, 2, emu="fp8")
+    assert torch.equal(tgt.cpu(), te) and rel_l2(pred, pe) < 1e-2
+    wl = O.l1_loss_mean(pe, te)
+    wl.backward()
+    assert abs(float(loss) - float(wl)) < 1e-2 * float(wl)
+    for k, p in model.named_parameters():
+        assert rel_l2(p.grad, leaves[k].grad) < 6e-2, (k, rel_l2(p.grad, leaves[k].grad))
+    # the weight images follow the optimizer: a few fused steps on one batch reduce the loss
+    opt = FusedAdamW(model.flat_store(), lr=1e-3, weight_decay=0.0)
+    torch.manual_seed(9)
+    l0 = float(model.train_step(x.to(DEV), opt))
+    for _ in range(8):
+        torch.manual_seed(9)
+        l1 = float(model.train_step(x.to(DEV), opt))
+    assert abs(l0 - float(loss)) < 1e-4 * abs(float(loss)) and l1 < l0
+
+
+def test_vit_l_shaped_blocks_fp8(fp8_operands):
+    """configs[4] geometry: D = 1024, 16 heads, F = 4096, N = 196, two blocks, two images, against the oracle."""
+    from vit_core.ssl.simmim import SimMIMViT
+    from vit_core.ssl.simmim.masking import draw_mask
+    from oracle import vit_oracle as O
+    torch.manual_seed(7)
+    model = SimMIMViT(num_blocks=2, input_shape=(3, 224, 224), embed_dim=1024, patch_size=16, num_heads=16, mlp_dim=4096,
+                      dropout=0.0, mask_ratio=0.6)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV).train()
+    x = torch.rand(2, 3, 224, 224, generator=torch.Generator().manual_seed(8))
+    torch.manual_seed(9)
+    pred, tgt = model(x.to(DEV))
+    loss = torch.nn.functional.l1_loss(pred, tgt)
+    loss.backward()
+    torch.manual_seed(9)
+    mask = draw_mask(2, 196, 0.6)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    pe, te = O.simmim_forward(leaves, x, mask, 16, 16, emu="fp8")
+    assert torch.equal(tgt.cpu(), te) and rel_l2(pred, pe) < 1e-2
+    wl = O.l1_loss_mean(pe, te)
+    wl.backward()
+    assert abs(float(loss) - float(wl)) < 1e-2 * float(wl)
+    for k, p in model.named_parameters():
+        assert rel_l2(p.grad, leaves[k].grad) < 6e-2, (k, rel_l2(p.grad, leaves[k].grad))
+    with torch.no_grad():
+        p32, _ = O.simmim_forward(sd, x, mask, 16, 16)
+    assert rel_l2(pred, p32) < 8e-2                   # vs pure fp32: e4m3 operand rounding through two blocks

@@ -5,7 +5,7 @@ ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$ROOT/tools/build"; mkdir -p "$OUT/$1"
 CS="$ROOT/vit-ssl_amd/csrc"
 objs=()
-for f in error.cpp gemm_nt.hip gemm_tn.hip layernorm.hip attention.hip elementwise.hip dino.hip augment.hip; do
+for f in error.cpp gemm_nt.hip gemm_tn.hip layernorm.hip attention.hip elementwise.hip dino.hip augment.hip fp8.hip; do
   extra=""; [ "$f" = augment.hip ] && extra="-ffp-contract=off"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result $2 $extra -x hip -c "$CS/$f" -o "$OUT/$1/$f.o" &
   objs+=("$OUT/$1/$f.o")

@@ -33,6 +33,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef unsigned short bf16_t;  // raw storage
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -53,6 +54,18 @@ __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, v);
 }
 __device__ __forceinline__ float round_bf(float f) { return bf2f(f2bf(f)); }
+
+// four fp32 -> four OCP e4m3fn bytes (round to nearest even, saturating at +-448: the
+// conversion instruction is given clamped inputs), element 0 in the low byte
+__device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d) {
+  a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f);
+  b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
+  c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f);
+  d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return (unsigned)w;
+}
 
 // ---------------------------------------------------------------- wave reductions (64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {

@@ -1,0 +1,129 @@
+// OCP e4m3fn operand images for the fp8 forward GEMMs (gfx950; BASELINE.json configs[4]).
+//
+// Activations are quantised at unit scale (LayerNorm / attention / GELU outputs are O(1); +-448 saturates),
+// weights per tensor with a power-of-two scale 2^k, k = floor(log2(448 / max|w|)): multiplying by a power
+// of two is exact in fp32, so e4m3(w * 2^k) * 2^-k is w rounded to 4 significant bits and nothing else.
+// All kernels are HBM streams: 16-byte loads, 4- or 8-byte stores per lane.
+#include "common.h"
+
+namespace {
+
+constexpr int Q_THREADS = 256;
+constexpr int W_CHUNK = 4096;   // weight elements per workgroup of the batched kernels (16 per thread)
+
+__global__ __launch_bounds__(Q_THREADS) void quantize_fp8_kernel(const bf16_t* __restrict__ x, unsigned char* __restrict__ y,
+                                                                 long long n) {
+  const long long n8 = n >> 3;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    const u32x4 v = *(const u32x4*)(x + 8 * i);
+    u32x2 o;
+    o[0] = pack_fp8x4(bf_lo(v[0]), bf_hi(v[0]), bf_lo(v[1]), bf_hi(v[1]));
+    o[1] = pack_fp8x4(bf_lo(v[2]), bf_hi(v[2]), bf_lo(v[3]), bf_hi(v[3]));
+    *(u32x2*)(y + 8 * i) = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+    const long long i = (n8 << 3) + threadIdx.x;
+    y[i] = (unsigned char)(pack_fp8x4(bf2f(x[i]), 0.f, 0.f, 0.f) & 0xffu);
+  }
+}
+
+__device__ __forceinline__ int find_job(const int* __restrict__ chunk_start, int njobs, int b) {
+  int lo = 0, hi = njobs;              // chunk_start[lo] <= b < chunk_start[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (chunk_start[mid] <= b) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// max |w| per tensor: non-negative floats order like their bit patterns, so the per-tensor reduction is one
+// atomicMax on the bits per workgroup
+__global__ __launch_bounds__(Q_THREADS) void fp8_weight_amax_kernel(const vitssl_fp8_weight_job_t* __restrict__ jobs,
+                                                                    const int* __restrict__ chunk_start, int njobs,
+                                                                    float* __restrict__ amax) {
+  __shared__ float red[Q_THREADS / 64];
+  const int j = find_job(chunk_start, njobs, blockIdx.x);
+  const vitssl_fp8_weight_job_t job = jobs[j];
+  const long long base = (long long)(blockIdx.x - chunk_start[j]) * W_CHUNK;
+  float m = 0.f;
+#pragma unroll
+  for (int it = 0; it < W_CHUNK / (4 * Q_THREADS); ++it) {
+    const long long i = base + 4ll * (it * Q_THREADS + threadIdx.x);
+    if (i + 3 < job.n) {
+      const f32x4 v = *(const f32x4*)(job.src + i);
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    } else {
+      for (long long e = i; e < job.n; ++e) m = fmaxf(m, fabsf(job.src[e]));
+    }
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    atomicMax((unsigned*)amax + j, __float_as_uint(m));
+  }
+}
+
+// k = floor(log2(448 / amax)), clamped so that 2^k and 2^-k are normal floats
+__device__ __forceinline__ int fp8_scale_exp(float amax) {
+  if (!(amax > 0.f) || !(amax < 3.0e38f)) return 0;
+  int e;
+  const float fr = frexpf(amax, &e);           // amax = fr * 2^e, fr in [0.5, 1)
+  // 448 = 0.875 * 2^9: 448 / amax = (0.875 / fr) * 2^(9 - e), and 0.875 / fr is in (0.875, 1.75]
+  int k = 9 - e + (fr <= 0.875f ? 0 : -1);
+  k = k > 120 ? 120 : (k < -120 ? -120 : k);
+  return k;
+}
+
+__global__ __launch_bounds__(Q_THREADS) void fp8_weight_quant_kernel(const vitssl_fp8_weight_job_t* __restrict__ jobs,
+                                                                     const int* __restrict__ chunk_start, int njobs,
+                                                                     const float* __restrict__ amax, float* __restrict__ alpha) {
+  const int j = find_job(chunk_start, njobs, blockIdx.x);
+  const vitssl_fp8_weight_job_t job = jobs[j];
+  const int k = fp8_scale_exp(amax[j]);
+  const float sc = ldexpf(1.0f, k);
+  if (blockIdx.x == chunk_start[j] && threadIdx.x == 0) alpha[j] = ldexpf(1.0f, -k);
+  unsigned char* dst = (unsigned char*)job.dst_fp8;
+  const long long base = (long long)(blockIdx.x - chunk_start[j]) * W_CHUNK;
+#pragma unroll
+  for (int it = 0; it < W_CHUNK / (4 * Q_THREADS); ++it) {
+    const long long i = base + 4ll * (it * Q_THREADS + threadIdx.x);
+    if (i + 3 < job.n) {
+      const f32x4 v = *(const f32x4*)(job.src + i) * sc;
+      *(unsigned*)(dst + i) = pack_fp8x4(v[0], v[1], v[2], v[3]);
+    } else {
+      for (long long e = i; e < job.n; ++e) dst[e] = (unsigned char)(pack_fp8x4(job.src[e] * sc, 0.f, 0.f, 0.f) & 0xffu);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int vitssl_quantize_fp8(const void* x_bf16, void* y_fp8, int64_t n, void* stream) {
+  VS_CHECK_ARG(x_bf16 && y_fp8 && n > 0, "quantize_fp8: bad args");
+  VS_CHECK_ARG(((uintptr_t)x_bf16 & 15) == 0 && ((uintptr_t)y_fp8 & 7) == 0, "quantize_fp8: pointers must be 16- / 8-byte aligned");
+  long long blocks = (n / 8 + Q_THREADS - 1) / Q_THREADS;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(quantize_fp8_kernel, dim3((unsigned)blocks), dim3(Q_THREADS), 0, (hipStream_t)stream, (const bf16_t*)x_bf16,
+                     (unsigned char*)y_fp8, (long long)n);
+  VS_CHECK_LAUNCH("quantize_fp8");
+  return VITSSL_OK;
+}
+
+extern "C" int vitssl_fp8_quantize_weights(const vitssl_fp8_weight_job_t* jobs, const int* chunk_start, int njobs, int total_chunks,
+                                           float* amax_ws, float* alpha, void* stream) {
+  VS_CHECK_ARG(jobs && chunk_start && amax_ws && alpha && njobs > 0 && total_chunks > 0, "fp8_quantize_weights: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(amax_ws, 0, sizeof(float) * (size_t)njobs, s);
+  if (e != hipSuccess) {
+    vitssl_set_error("fp8_quantize_weights: memset failed: %s", hipGetErrorString(e));
+    return VITSSL_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(fp8_weight_amax_kernel, dim3(total_chunks), dim3(Q_THREADS), 0, s, jobs, chunk_start, njobs, amax_ws);
+  VS_CHECK_LAUNCH("fp8_weight_amax");
+  hipLaunchKernelGGL(fp8_weight_quant_kernel, dim3(total_chunks), dim3(Q_THREADS), 0, s, jobs, chunk_start, njobs, amax_ws, alpha);
+  VS_CHECK_LAUNCH("fp8_weight_quant");
+  return VITSSL_OK;
+}

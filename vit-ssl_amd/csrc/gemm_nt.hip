@@ -112,6 +112,9 @@ struct NtParams {
   int group_n;   // tile columns per raster group (their B panels stay L2-resident)
   int k_chunk;   // split-K: K elements per blockIdx.y slice (0 = no split)
   int stagger;   // ping-pong kernel: estimated time of one output tile in 100 MHz ticks (0 = no start-up stagger)
+  int esz;       // operand element size in bytes: 2 = bf16, 1 = fp8 e4m3 (ping-pong kernel only)
+  const float* alpha;   // fp8 operands: device scalar multiplied into the accumulators (product of the dequantisation scales), or NULL
+  void* out2;    // fp8 operands, EPI_GELU: optional e4m3 image of out1 (the next GEMM's A operand), or NULL
 #ifdef VITSSL_NT_STAMPS
   unsigned long long* stamps;   // diagnostic build only (tools/nt_stamps.py): [wg][2 wave groups][16 rounds][4] x 100 MHz ticks
 #endif
@@ -158,7 +161,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // Fused epilogue of one 128x64 wave tile (shared by both main-loop variants).
-template <int EPI, typename CFG>
+template <int EPI, typename CFG, bool Q8 = false>
 __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][CFG::MI], const long long m0, const int n0,
                                             const int wm, const int wn, const int lane) {
   constexpr int MI = CFG::MI;
@@ -279,7 +282,9 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), rs, off_elem(i, nnp[1], 4u), 0, F32_AUX);
     }
   };
-  __amdgpu_buffer_rsrc_t rsOut0, rsOut1, rsAux;
+  __amdgpu_buffer_rsrc_t rsOut0, rsOut1, rsOut2, rsAux;
+  const bool q8 = Q8 && EPI == VITSSL_EPI_GELU && p.out2 != nullptr;
+  if (q8) rsOut2 = window(p.out2, 1);
   if constexpr (EPI == VITSSL_EPI_BF16 || EPI == VITSSL_EPI_GELU || EPI == VITSSL_EPI_DGELU) rsOut0 = window(p.out0, 2);
   if constexpr (EPI == VITSSL_EPI_F32 || EPI == VITSSL_EPI_RESID) rsOut0 = window(p.out0, 4);
   if constexpr (EPI == VITSSL_EPI_GELU) rsOut1 = window(p.out1, 2);
@@ -373,6 +378,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
       const long long m = m0 + wm * CFG::WROWS + i * 16 + (lane & 15);
       const bool okm = m < p.M;
       u32x2 out_a[2][2], out_b[2][2];   // bf16 images of this row, both pairs: stored together below
+      unsigned out_q[2][2];             // e4m3 image of out_b (fp8 operand path)
 #pragma unroll
       for (int jp = 0; jp < 2; ++jp) {
         f32x4 v[2] = {acc[2 * jp][i] + bias4[jp][0], acc[2 * jp + 1][i] + bias4[jp][1]};
@@ -401,6 +407,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
             }
             out_b[jp][h] = u32x2{pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
             out_a[jp][h] = u32x2{pack_bf2(d[0], d[1]), pack_bf2(d[2], d[3])};
+            if constexpr (Q8) out_q[jp][h] = pack_fp8x4(y[0], y[1], y[2], y[3]);
           }
         } else if constexpr (EPI == VITSSL_EPI_DGELU) {
           // du = acc * g'  (g' already carries the dropout mask and its scale)
@@ -460,6 +467,15 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
         store_bf16_row(rsOut0, i, out_a, IC<(EPI == VITSSL_EPI_GELU && NT_STORE_AUX == 0) ? NT_GPRIME_AUX : BF16_AUX>{});
       }
       if constexpr (EPI == VITSSL_EPI_GELU) store_bf16_row(rsOut1, i, out_b, IC<BF16_AUX>{});
+      if constexpr (Q8 && EPI == VITSSL_EPI_GELU) {
+        if (q8) {
+#pragma unroll
+          for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+              __builtin_amdgcn_raw_buffer_store_b32(out_q[jp][h], rsOut2, off_elem(i, nn[jp][h], 1u), 0, BF16_AUX);
+        }
+      }
     }
   }
 
@@ -677,13 +693,19 @@ __device__ __forceinline__ void wait_vmcnt_exact() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// two 16-byte fragments of one tile row -> the 32-byte operand of the K = 128 fp8 MFMA
+__device__ __forceinline__ i32x8 join_frags(const bf16x8& lo, const bf16x8& hi) {
+  const u32x4 a = __builtin_bit_cast(u32x4, lo), b = __builtin_bit_cast(u32x4, hi);
+  return i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+}
+
 // (target builtins with immediate operands are kept out of the kernel's lambdas: on the host pass a
 // lambda body is checked eagerly and the kernel would silently lose its stub)
 __device__ __forceinline__ void dma16_to_lds(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, unsigned voffset) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_wave_base), 16, voffset, 0, 0, 0);
 }
 
-template <int EPI, typename CFG>
+template <int EPI, typename CFG, bool F8 = false>
 __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_nt_pp_kernel(NtParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   static_assert(CFG::BK == 64 && CFG::WM == 2 && CFG::WN == 4, "ping-pong loop is written for 8 waves, BK = 64");
@@ -736,12 +758,17 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_nt_pp_kernel(NtParams p)
     }   // the other waves are held by the prologue's barrier
   }
 
-  const unsigned long long a_bytes = (unsigned long long)p.M * p.K * 2ull;
-  const unsigned long long b_bytes = (unsigned long long)p.N * p.K * 2ull;
+  // A K-tile is 128 BYTES of every operand row: 64 bf16 or 128 e4m3 elements.  Staging, LDS layout and
+  // fragment reads are byte-identical for the two operand types; the fp8 form hands the two 16-byte
+  // fragments of a row to ONE v_mfma_f32_16x16x128_f8f6f4 (its k order inside the tile is a permutation
+  // applied to both operands alike, which a contraction does not see).
+  constexpr unsigned ESZ = F8 ? 1u : 2u;
+  const unsigned long long a_bytes = (unsigned long long)p.M * p.K * ESZ;
+  const unsigned long long b_bytes = (unsigned long long)p.N * p.K * ESZ;
   __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)a_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)b_bytes, 0x00020000);
-  const int nk = p.K / 64;
-  const unsigned rowb = (unsigned)p.K * 2u;            // bytes per operand row
+  const int nk = F8 ? p.K / 128 : p.K / 64;
+  const unsigned rowb = (unsigned)p.K * ESZ;           // bytes per operand row
 
   // ---- staging slots: every wave issues exactly 2 DMA instructions per unit (8 rows x 128 B each)
   // unit A_h: rows g*WROWS + 64 h + 8 q (+ lane/8); unit B_h: rows 64 c + 32 h + 8 q
@@ -862,14 +889,25 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_nt_pp_kernel(NtParams p)
       return;
     }
     __builtin_amdgcn_s_setprio(1);
+    if constexpr (F8) {
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
+      for (int jj = 0; jj < 2; ++jj) {
+        const i32x8 bq = join_frags(fb[nh][0][jj], fb[nh][1][jj]);
 #pragma unroll
         for (int ii = 0; ii < cnt; ++ii)
-          acc[2 * nh + jj][4 * mh + ii] =
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nh][kk][jj], fa[kk][ii], acc[2 * nh + jj][4 * mh + ii], 0, 0, 0);
+          acc[2 * nh + jj][4 * mh + ii] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+              bq, join_frags(fa[0][ii], fa[1][ii]), acc[2 * nh + jj][4 * mh + ii], 0, 0, 0, 0, 0, 0);   // e4m3 x e4m3, scales 0 = unscaled form
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int ii = 0; ii < cnt; ++ii)
+            acc[2 * nh + jj][4 * mh + ii] =
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nh][kk][jj], fa[kk][ii], acc[2 * nh + jj][4 * mh + ii], 0, 0, 0);
+    }
     __builtin_amdgcn_s_setprio(0);
   };
   auto section = [&]() {                               // end of a LOAD or COMPUTE part
@@ -957,7 +995,16 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_nt_pp_kernel(NtParams p)
       buf ^= 1;
     }
     stamp(round, 1);
-    nt_epilogue<EPI, CFG>(p, acc, m0, n0, wm, wn, lane);
+    if constexpr (F8) {
+      if (p.alpha) {
+        const float al = *p.alpha;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < MI; ++i) acc[j][i] *= al;
+      }
+    }
+    nt_epilogue<EPI, CFG, F8>(p, acc, m0, n0, wm, wn, lane);
     stamp(round, 2);
 #ifdef VITSSL_NT_STAMPS
     if (p.stamps) {                                    // diagnostic: when have this wave's stores been acknowledged?
@@ -992,12 +1039,12 @@ int nt_pp_enabled() {
   return v;
 }
 
-template <int EPI, typename CFG>
+template <int EPI, typename CFG, bool F8 = false>
 int launch_pp(NtParams p, hipStream_t s) {
   constexpr int LDS = 2 * CFG::BUF_BYTES + 1024;
   static bool attr_done = false;  // idempotent; a benign race sets the same value
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, CFG, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       vitssl_set_error("gemm_nt: cannot raise dynamic LDS to %d: %s", LDS, hipGetErrorString(e));
       return VITSSL_ERR_LAUNCH;
@@ -1017,9 +1064,9 @@ int launch_pp(NtParams p, hipStream_t s) {
   }
   const float epi_us = EPI == VITSSL_EPI_BF16 ? 2.f : EPI == VITSSL_EPI_GELU ? 7.f : EPI == VITSSL_EPI_DGELU ? 5.f
                        : EPI == VITSSL_EPI_RESID ? 8.f : 4.f;
-  const float tile_us = (float)(p.K / 64) * 1.45f * (float)CFG::MI / 8.f + epi_us;
+  const float tile_us = (float)(p.K * p.esz / 128) * 1.45f * (float)CFG::MI / 8.f + epi_us;
   p.stagger = (int)(stagger_scale * tile_us * 100.f);
-  hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, CFG>), dim3((unsigned)grid), dim3(CFG::THREADS), LDS, s, p);
+  hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, CFG, F8>), dim3((unsigned)grid), dim3(CFG::THREADS), LDS, s, p);
   VS_CHECK_LAUNCH("gemm_nt_pp");
   return VITSSL_OK;
 }
@@ -1038,7 +1085,7 @@ int launch_cfg(NtParams p, hipStream_t s) {
   }
   p.tiles_m = (int)ceil_div64(p.M, CFG::BM);
   p.tiles_n = (int)ceil_div64(p.N, CFG::BN);
-  const int want = (int)((2 * 1024 * 1024) / ((long long)CFG::BN * p.K * 2));   // panels of a group <= ~2 MiB of L2
+  const int want = (int)((2 * 1024 * 1024) / ((long long)CFG::BN * p.K * p.esz));   // panels of a group <= ~2 MiB of L2
   static int group_knob = -1;                          // VITSSL_NT_GROUPN: force the raster group width (developer knob)
   if (group_knob < 0) {
     const char* e = getenv("VITSSL_NT_GROUPN");
@@ -1051,6 +1098,16 @@ int launch_cfg(NtParams p, hipStream_t s) {
   else if (p.tiles_n % 4 == 0) p.group_n = 4;
   else if (p.tiles_n % 3 == 0) p.group_n = 3;
   else p.group_n = want < 4 ? want : 4;
+  if (p.esz == 1) {
+    // fp8 operands exist for the ping-pong loop and the epilogues of the transformer-block forward only
+    if constexpr (CFG::WAVES == 8 && CFG::BK == 64 &&
+                  (EPI == VITSSL_EPI_BF16 || EPI == VITSSL_EPI_F32 || EPI == VITSSL_EPI_GELU || EPI == VITSSL_EPI_RESID)) {
+      return launch_pp<EPI, CFG, true>(p, s);
+    } else {
+      vitssl_set_error("gemm_fp8_nt: epilogue %d / tile configuration not built for fp8 operands", EPI);
+      return VITSSL_ERR_ARG;
+    }
+  }
   if constexpr (CFG::WAVES == 8 && CFG::BK == 64 && EPI != EPI_F32_SPLITK) {
     if (nt_pp_enabled() && p.k_chunk == 0) return launch_pp<EPI, CFG>(p, s);
   }
@@ -1115,13 +1172,13 @@ int launch_splitk_f32(NtParams p, hipStream_t s, bool* done) {
 template <int EPI>
 int launch_nt(const NtParams& p, hipStream_t s) {
   if constexpr (EPI == VITSSL_EPI_F32) {
-    if (!p.colsum) {
+    if (!p.colsum && p.esz == 2) {
       bool done = false;
       const int rc = launch_splitk_f32(p, s, &done);
       if (rc != VITSSL_OK || done) return rc;
     }
   }
-  const int mode = nt_tile_override();
+  const int mode = p.esz == 1 ? 0 : nt_tile_override();
   if (mode == 1) return launch_cfg<EPI, NtBig>(p, s);
   if (mode == 2) return launch_cfg<EPI, NtSmall>(p, s);
   if (mode == 3) return launch_cfg<EPI, NtBig192>(p, s);
@@ -1129,7 +1186,7 @@ int launch_nt(const NtParams& p, hipStream_t s) {
   // Measured on MI355X (tools/bench_gemm.py, round 1): SMALL loses 10-25 % on every ViT-B
   // shape, heavy epilogues included; it only pays for grids too small to fill the chip.
   const long long big_tiles = ceil_div64(p.M, 256) * ceil_div64(p.N, 256);
-  if (big_tiles < 64) return launch_cfg<EPI, NtSmall>(p, s);
+  if (big_tiles < 64 && p.esz == 2) return launch_cfg<EPI, NtSmall>(p, s);
   // (N = 384, ViT-S: three exact 128-wide SMALL columns instead of two 256-wide ones with the
   // second half empty were measured too: 21.1 vs 20.9 ms per step, not worth it.)
   //
@@ -1154,14 +1211,15 @@ static unsigned long long* g_nt_stamps = nullptr;
 extern "C" void vitssl_debug_nt_stamps(void* buf) { g_nt_stamps = (unsigned long long*)buf; }
 #endif
 
-extern "C" int vitssl_gemm_bf16_nt(const vitssl_gemm_t* g, void* stream) {
-  VS_CHECK_ARG(g && g->A && g->B && g->out0, "gemm_nt: null operand");
-  VS_CHECK_ARG(g->M > 0 && g->N > 0 && g->K > 0, "gemm_nt: empty problem M=%lld N=%d K=%d", (long long)g->M, g->N, g->K);
-  VS_CHECK_ARG(g->K % 64 == 0, "gemm_nt: K=%d must be a multiple of 64", g->K);
-  VS_CHECK_ARG(g->N % 4 == 0, "gemm_nt: N=%d must be a multiple of 4", g->N);
-  VS_CHECK_ARG(g->N <= (1 << 20), "gemm_nt: N=%d exceeds 2^20 (epilogue windows use 32-bit byte offsets)", g->N);
-  VS_CHECK_ARG((unsigned long long)g->M * g->K * 2ull < (1ull << 31) && (unsigned long long)g->N * g->K * 2ull < (1ull << 31),
-               "gemm_nt: operand larger than 2 GiB (M=%lld N=%d K=%d)", (long long)g->M, g->N, g->K);
+static int gemm_nt_entry(const vitssl_gemm_t* g, int esz, const vitssl_fp8_gemm_t* q, void* stream) {
+  const char* who = esz == 1 ? "gemm_fp8_nt" : "gemm_nt";
+  VS_CHECK_ARG(g && g->A && g->B && g->out0, "%s: null operand", who);
+  VS_CHECK_ARG(g->M > 0 && g->N > 0 && g->K > 0, "%s: empty problem M=%lld N=%d K=%d", who, (long long)g->M, g->N, g->K);
+  VS_CHECK_ARG(g->K % (128 / esz) == 0, "%s: K=%d must be a multiple of %d", who, g->K, 128 / esz);
+  VS_CHECK_ARG(g->N % 4 == 0, "%s: N=%d must be a multiple of 4", who, g->N);
+  VS_CHECK_ARG(g->N <= (1 << 20), "%s: N=%d exceeds 2^20 (epilogue windows use 32-bit byte offsets)", who, g->N);
+  VS_CHECK_ARG((unsigned long long)g->M * g->K * (unsigned)esz < (1ull << 31) && (unsigned long long)g->N * g->K * (unsigned)esz < (1ull << 31),
+               "%s: operand larger than 2 GiB (M=%lld N=%d K=%d)", who, (long long)g->M, g->N, g->K);
   NtParams p;
   p.A = (const bf16_t*)g->A;
   p.B = (const bf16_t*)g->B;
@@ -1179,6 +1237,9 @@ extern "C" int vitssl_gemm_bf16_nt(const vitssl_gemm_t* g, void* stream) {
   p.tiles_m = p.tiles_n = p.group_n = 0;   // set per tile configuration in launch_cfg
   p.k_chunk = 0;
   p.stagger = 0;
+  p.esz = esz;
+  p.alpha = q ? q->alpha : nullptr;
+  p.out2 = q ? q->out_fp8 : nullptr;
 #ifdef VITSSL_NT_STAMPS
   p.stamps = g_nt_stamps;
 #endif
@@ -1187,21 +1248,31 @@ extern "C" int vitssl_gemm_bf16_nt(const vitssl_gemm_t* g, void* stream) {
     case VITSSL_EPI_BF16: return launch_nt<VITSSL_EPI_BF16>(p, s);
     case VITSSL_EPI_F32: return launch_nt<VITSSL_EPI_F32>(p, s);
     case VITSSL_EPI_GELU:
-      VS_CHECK_ARG(g->out1, "gemm_nt: EPI_GELU needs out1");
+      VS_CHECK_ARG(g->out1, "%s: EPI_GELU needs out1", who);
       return launch_nt<VITSSL_EPI_GELU>(p, s);
     case VITSSL_EPI_RESID:
-      VS_CHECK_ARG(g->aux, "gemm_nt: EPI_RESID needs aux (residual)");
+      VS_CHECK_ARG(g->aux, "%s: EPI_RESID needs aux (residual)", who);
       return launch_nt<VITSSL_EPI_RESID>(p, s);
     case VITSSL_EPI_DGELU:
-      VS_CHECK_ARG(g->aux, "gemm_nt: EPI_DGELU needs aux (pre-activation)");
+      VS_CHECK_ARG(g->aux, "%s: EPI_DGELU needs aux (pre-activation)", who);
       return launch_nt<VITSSL_EPI_DGELU>(p, s);
     case VITSSL_EPI_EMBED:
       VS_CHECK_ARG(g->embed.pos && g->embed.tokens > 0 && g->embed.out_tokens >= g->embed.tokens + g->embed.tok_offset,
-                   "gemm_nt: EPI_EMBED needs pos/tokens");
-      VS_CHECK_ARG(!g->embed.mask || g->embed.mask_token, "gemm_nt: EPI_EMBED mask without mask_token");
+                   "%s: EPI_EMBED needs pos/tokens", who);
+      VS_CHECK_ARG(!g->embed.mask || g->embed.mask_token, "%s: EPI_EMBED mask without mask_token", who);
       return launch_nt<VITSSL_EPI_EMBED>(p, s);
     default:
-      vitssl_set_error("gemm_nt: unknown epilogue %d", g->epilogue);
+      vitssl_set_error("%s: unknown epilogue %d", who, g->epilogue);
       return VITSSL_ERR_ARG;
   }
+}
+
+extern "C" int vitssl_gemm_bf16_nt(const vitssl_gemm_t* g, void* stream) { return gemm_nt_entry(g, 2, nullptr, stream); }
+
+extern "C" int vitssl_gemm_fp8_nt(const vitssl_gemm_t* g, const vitssl_fp8_gemm_t* q, void* stream) {
+  VS_CHECK_ARG(g && (g->epilogue == VITSSL_EPI_BF16 || g->epilogue == VITSSL_EPI_F32 || g->epilogue == VITSSL_EPI_GELU ||
+                     g->epilogue == VITSSL_EPI_RESID),
+               "gemm_fp8_nt: fp8 operands are built for the BF16 / F32 / GELU / RESID epilogues");
+  VS_CHECK_ARG(!g->colsum, "gemm_fp8_nt: column sums are a backward-pass feature (bf16 operands)");
+  return gemm_nt_entry(g, 1, q, stream);
 }

@@ -27,11 +27,12 @@ constexpr int LN_THREADS = 256;  // 4 waves = 4 rows in flight per block
 #define LN_FWD_PAIR 0
 #endif
 
-template <int V>
+// Q8: also emit the e4m3 image of the output (fp8 operand path, unit scale)
+template <int V, bool Q8 = false>
 __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                             float* __restrict__ mean, float* __restrict__ rstd,
-                                                            long long rows, int cols, float eps) {
+                                                            long long rows, int cols, float eps, unsigned char* __restrict__ y8 = nullptr) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int c4n = cols >> 2;
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restr
       rstd[row] = rs;
     }
     bf16_t* yr = y + row * cols;
-    if (LN_FWD_PAIR && V >= 2 && c4n == 64 * V) {
+    if (LN_FWD_PAIR && !Q8 && V >= 2 && c4n == 64 * V) {
       u32x2 w[V];
 #pragma unroll
       for (int v = 0; v < V; ++v) {
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restr
         const f32x4 o = xv[v] * rs * g[v] + b[v];
         u32x2 w = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
         *(u32x2*)(yr + 4 * c4) = w;
+        if constexpr (Q8) *(unsigned*)(y8 + row * cols + 4 * c4) = pack_fp8x4(o[0], o[1], o[2], o[3]);
       }
     }
   }
@@ -257,8 +259,8 @@ extern "C" int vitssl_layernorm_fwd(const float* x, const float* gamma, const fl
   const int grid = ln_grid(rows, true);
   hipStream_t s = (hipStream_t)stream;
 #define VS_LNF(V)                                                                                                   \
-  hipLaunchKernelGGL(ln_fwd_kernel<V>, dim3(grid), dim3(LN_THREADS), 0, s, x, gamma, beta, (bf16_t*)y_bf16, mean, rstd, \
-                     (long long)rows, cols, eps)
+  hipLaunchKernelGGL((ln_fwd_kernel<V, false>), dim3(grid), dim3(LN_THREADS), 0, s, x, gamma, beta, (bf16_t*)y_bf16, mean, rstd, \
+                     (long long)rows, cols, eps, (unsigned char*)nullptr)
   if (cols <= 256) VS_LNF(1);
   else if (cols <= 512) VS_LNF(2);
   else if (cols <= 768) VS_LNF(3);
@@ -266,6 +268,25 @@ extern "C" int vitssl_layernorm_fwd(const float* x, const float* gamma, const fl
   else VS_LNF(8);
 #undef VS_LNF
   VS_CHECK_LAUNCH("layernorm_fwd");
+  return VITSSL_OK;
+}
+
+extern "C" int vitssl_layernorm_fwd_fp8(const float* x, const float* gamma, const float* beta, void* y_bf16, void* y_fp8,
+                                        float* mean, float* rstd, int64_t rows, int cols, float eps, void* stream) {
+  VS_CHECK_ARG(x && gamma && beta && y_bf16 && y_fp8 && mean && rstd, "layernorm_fwd_fp8: null pointer");
+  VS_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 2048, "layernorm_fwd_fp8: cols=%d must be a multiple of 4 and <= 2048", cols);
+  const int grid = ln_grid(rows, true);
+  hipStream_t s = (hipStream_t)stream;
+#define VS_LNF(V)                                                                                                         \
+  hipLaunchKernelGGL((ln_fwd_kernel<V, true>), dim3(grid), dim3(LN_THREADS), 0, s, x, gamma, beta, (bf16_t*)y_bf16, mean, rstd, \
+                     (long long)rows, cols, eps, (unsigned char*)y_fp8)
+  if (cols <= 256) VS_LNF(1);
+  else if (cols <= 512) VS_LNF(2);
+  else if (cols <= 768) VS_LNF(3);
+  else if (cols <= 1024) VS_LNF(4);
+  else VS_LNF(8);
+#undef VS_LNF
+  VS_CHECK_LAUNCH("layernorm_fwd_fp8");
   return VITSSL_OK;
 }
 

@@ -29,6 +29,10 @@ class Gemm(C.Structure):
                 ("out1", C.c_void_p), ("colsum", C.c_void_p), ("drop", Dropout), ("embed", Embed)]
 
 
+class Fp8Gemm(C.Structure):
+    _fields_ = [("alpha", C.c_void_p), ("out_fp8", C.c_void_p)]
+
+
 EPI_BF16, EPI_F32, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_EMBED = range(6)
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -41,6 +45,10 @@ PROTOTYPES = {
     "vitssl_grad_mask_cast": [_vp, _vp, _vp, Dropout, _i64, _i, _vp],
     "vitssl_gemm_bf16_nt": [C.POINTER(Gemm), _vp],
     "vitssl_gemm_bf16_tn": [_vp, _vp, _vp, _i64, _i, _i, _vp, _i64, _vp],
+    "vitssl_gemm_fp8_nt": [C.POINTER(Gemm), C.POINTER(Fp8Gemm), _vp],
+    "vitssl_quantize_fp8": [_vp, _vp, _i64, _vp],
+    "vitssl_layernorm_fwd_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _vp],
+    "vitssl_fp8_quantize_weights": [_vp, _vp, _i, _i, _vp, _vp, _vp],
     "vitssl_attn_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "vitssl_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "vitssl_patchify_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _vp],

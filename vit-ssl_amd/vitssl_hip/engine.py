@@ -25,7 +25,29 @@ from . import ops
 
 BF16 = torch.bfloat16
 F32 = torch.float32
+FP8 = ops.FP8
 ALIGN = 64  # elements; keeps every parameter 256-byte aligned inside the flat buffer
+
+# Operand type of the FORWARD Linear products inside the encoder blocks: "bf16" (default, the reference's
+# autocast contract) or "fp8" (OCP e4m3, BASELINE.json configs[4]; backward products stay bf16).  Read when an
+# EncoderStack is built: set VITSSL_LINEAR_OPERANDS=fp8 or call set_linear_operands("fp8") before the model's
+# first forward.
+import os as _os
+
+_LINEAR_OPERANDS = _os.environ.get("VITSSL_LINEAR_OPERANDS", "bf16")
+
+
+def set_linear_operands(kind: str):
+    global _LINEAR_OPERANDS
+    if kind not in ("bf16", "fp8"):
+        raise L.VitsslError(f"linear operands must be 'bf16' or 'fp8', got {kind!r}")
+    _LINEAR_OPERANDS = kind
+
+
+def linear_operands() -> str:
+    if _LINEAR_OPERANDS not in ("bf16", "fp8"):
+        raise L.VitsslError(f"VITSSL_LINEAR_OPERANDS must be 'bf16' or 'fp8', got {_LINEAR_OPERANDS!r}")
+    return _LINEAR_OPERANDS
 
 
 def _round_up(n: int, a: int) -> int:
@@ -84,7 +106,10 @@ class FlatStore:
         self._bf16: Dict[str, torch.Tensor] = {}
         self._bf16_key = None
         self.generation = 0   # bumped whenever the flat buffer is rewritten behind torch's back
-        self._cast_jobs: List[Tuple[str, Callable[[], torch.Tensor], bool]] = []
+        self._cast_jobs: List[Tuple[str, Callable[[], torch.Tensor], bool, bool]] = []
+        self._fp8: Dict[str, torch.Tensor] = {}
+        self._fp8_jobs: List[Tuple[str, Callable[[], torch.Tensor]]] = []
+        self._fp8_plan = None
 
     # ---- bookkeeping -------------------------------------------------------
     def is_attached(self) -> bool:
@@ -141,21 +166,26 @@ class FlatStore:
         return (self.generation, self.flat._version, pv)
 
     # ---- bf16 weight caches --------------------------------------------------
-    def register_weight(self, key: str, src: Callable[[], torch.Tensor], transposed_too: bool = True):
-        """Declare a 2-D GEMM weight [N,K]; caches `key` (bf16 [N,K]) and, if asked,
+    def register_weight(self, key: str, src: Callable[[], torch.Tensor], transposed_too: bool = True, plain: bool = True):
+        """Declare a 2-D GEMM weight [N,K]; caches `key` (bf16 [N,K], unless plain=False) and, if asked,
         `key + '.T'` (bf16 [K,N], the operand of the dgrad GEMM)."""
-        self._cast_jobs.append((key, src, transposed_too))
+        self._cast_jobs.append((key, src, transposed_too, plain))
+
+    def register_fp8_weight(self, key: str, src: Callable[[], torch.Tensor]):
+        """Declare a 2-D GEMM weight [N,K] whose forward operand is an e4m3 image with a per-tensor
+        power-of-two scale: `w8(key)` returns (image, dequantisation factor as a 1-element device tensor)."""
+        self._fp8_jobs.append((key, src))
 
     def refresh_weights(self):
         key = self.weights_key()
-        if key == self._bf16_key and self._bf16:
+        if key == self._bf16_key and (self._bf16 or self._fp8):
             return
         jobs = []
-        for key, src, tr in self._cast_jobs:
+        for key, src, tr, plain in self._cast_jobs:
             w = src()
             R, Cn = w.shape
-            dst = self._bf16.get(key)
-            if dst is None or dst.shape != (R, Cn):
+            dst = self._bf16.get(key) if plain else None
+            if plain and (dst is None or dst.shape != (R, Cn)):
                 dst = torch.empty(R, Cn, dtype=BF16, device=self.device)
                 self._bf16[key] = dst
             dst_t = None
@@ -169,10 +199,26 @@ class FlatStore:
             if getattr(self, "_cast_plan", None) is None:
                 self._cast_plan = ops.CastPlan()
             self._cast_plan.run(jobs)
+        if self._fp8_jobs:
+            jobs8 = []
+            for k8, src in self._fp8_jobs:
+                w = src()
+                dst = self._fp8.get(k8)
+                if dst is None or dst.shape != w.shape:
+                    dst = torch.empty(w.shape, dtype=FP8, device=self.device)
+                    self._fp8[k8] = dst
+                jobs8.append((w.contiguous(), dst))
+            if self._fp8_plan is None:
+                self._fp8_plan = ops.Fp8WeightPlan()
+            self._fp8_plan.run(jobs8)
         self._bf16_key = key
 
     def w(self, key: str) -> torch.Tensor:
         return self._bf16[key]
+
+    def w8(self, key: str) -> Tuple[torch.Tensor, torch.Tensor]:
+        j = next(i for i, (k8, _) in enumerate(self._fp8_jobs) if k8 == key)
+        return self._fp8[key], self._fp8_plan.alpha[j:j + 1]
 
 
 class GradReducer:
@@ -282,12 +328,22 @@ class EncoderStack:
         self.site_base = site_base
         self.ws = Workspace()
         self._saved = {}
+        self.fp8 = linear_operands() == "fp8"
+        if self.fp8 and (D % 128 != 0 or F % 128 != 0):
+            raise L.VitsslError(f"fp8 linear operands need embed_dim ({D}) and mlp_dim ({F}) to be multiples of 128")
         for b in self.bp:
             a = b + "self_attention."
-            store.register_weight(b + "wqkv", lambda a=a, D=D: store.span_view(a + "w_query.weight", a + "w_value.weight", (3 * D, D)))
-            store.register_weight(b + "wo", lambda a=a: store.view(a + "final_linear.weight", (D, D)))
-            store.register_weight(b + "w1", lambda b=b: store.view(b + "feed_forward.linear_in.weight", (F, D)))
-            store.register_weight(b + "w2", lambda b=b: store.view(b + "feed_forward.linear_out.weight", (D, F)))
+            srcs = {
+                "wqkv": lambda a=a, D=D: store.span_view(a + "w_query.weight", a + "w_value.weight", (3 * D, D)),
+                "wo": lambda a=a: store.view(a + "final_linear.weight", (D, D)),
+                "w1": lambda b=b: store.view(b + "feed_forward.linear_in.weight", (F, D)),
+                "w2": lambda b=b: store.view(b + "feed_forward.linear_out.weight", (D, F)),
+            }
+            for leaf, src in srcs.items():
+                # fp8 operands: the forward reads the e4m3 image, the dgrad GEMM still the bf16 transpose
+                store.register_weight(b + leaf, src, plain=not self.fp8)
+                if self.fp8:
+                    store.register_fp8_weight(b + leaf, src)
 
     # names ----------------------------------------------------------------
     def _n(self, i, leaf):
@@ -331,17 +387,33 @@ class EncoderStack:
             # LN input), otherwise ping-pong
             xout = g(f"{slot}.{i}.xout" if save else f"{slot}.tmp.xout{i & 1}", (M, D), F32, dev)
 
-            ops.layernorm_fwd(cur, st.view(self._n(i, "layer_norm1.weight")), st.view(self._n(i, "layer_norm1.bias")), h1, mean1, rstd1)
-            ops.gemm_nt(h1, st.w(self._n(i, "wqkv")), qkv, L.EPI_BF16)
             if return_attn and i == self.L - 1:
                 probs = torch.empty(B, H, T, T, dtype=F32, device=dev)
-            ops.attn_fwd(qkv, att, lse, B, T, H, dh, probs=probs if i == self.L - 1 else None)
-            ops.gemm_nt(att, st.w(self._n(i, "wo")), xmid, L.EPI_RESID, aux=cur, drop=self._drop(i, 0, seed, training))
-            ops.layernorm_fwd(xmid, st.view(self._n(i, "layer_norm2.weight")), st.view(self._n(i, "layer_norm2.bias")), h2, mean2, rstd2)
-            ops.gemm_nt(h2, st.w(self._n(i, "w1")), u, L.EPI_GELU, bias=st.view(self._n(i, "feed_forward.linear_in.bias")),
-                        out1=a, drop=self._drop(i, 1, seed, training))
-            ops.gemm_nt(a, st.w(self._n(i, "w2")), xout, L.EPI_RESID, bias=st.view(self._n(i, "feed_forward.linear_out.bias")),
-                        aux=xmid, drop=self._drop(i, 2, seed, training))
+            ln1 = (cur, st.view(self._n(i, "layer_norm1.weight")), st.view(self._n(i, "layer_norm1.bias")))
+            ln2 = (xmid, st.view(self._n(i, "layer_norm2.weight")), st.view(self._n(i, "layer_norm2.bias")))
+            b1, b2 = st.view(self._n(i, "feed_forward.linear_in.bias")), st.view(self._n(i, "feed_forward.linear_out.bias"))
+            if self.fp8:
+                # forward products on e4m3 operands: every producer also writes the e4m3 image of its output (transient,
+                # shared by all blocks); the bf16 images are still saved for the backward's weight-gradient GEMMs
+                x8 = g(f"{slot}.q8.d", (M, D), FP8, dev)
+                a8 = g(f"{slot}.q8.f", (M, F), FP8, dev)
+                (wq, aq), (wo, ao), (w1, a1), (w2, a2) = (st.w8(self._n(i, k)) for k in ("wqkv", "wo", "w1", "w2"))
+                ops.layernorm_fwd_fp8(*ln1, h1, x8, mean1, rstd1)
+                ops.gemm_fp8_nt(x8, wq, qkv, L.EPI_BF16, alpha=aq)
+                ops.attn_fwd(qkv, att, lse, B, T, H, dh, probs=probs if i == self.L - 1 else None)
+                ops.quantize_fp8(att, x8)
+                ops.gemm_fp8_nt(x8, wo, xmid, L.EPI_RESID, alpha=ao, aux=cur, drop=self._drop(i, 0, seed, training))
+                ops.layernorm_fwd_fp8(*ln2, h2, x8, mean2, rstd2)
+                ops.gemm_fp8_nt(x8, w1, u, L.EPI_GELU, alpha=a1, bias=b1, out1=a, out_fp8=a8, drop=self._drop(i, 1, seed, training))
+                ops.gemm_fp8_nt(a8, w2, xout, L.EPI_RESID, alpha=a2, bias=b2, aux=xmid, drop=self._drop(i, 2, seed, training))
+            else:
+                ops.layernorm_fwd(*ln1, h1, mean1, rstd1)
+                ops.gemm_nt(h1, st.w(self._n(i, "wqkv")), qkv, L.EPI_BF16)
+                ops.attn_fwd(qkv, att, lse, B, T, H, dh, probs=probs if i == self.L - 1 else None)
+                ops.gemm_nt(att, st.w(self._n(i, "wo")), xmid, L.EPI_RESID, aux=cur, drop=self._drop(i, 0, seed, training))
+                ops.layernorm_fwd(*ln2, h2, mean2, rstd2)
+                ops.gemm_nt(h2, st.w(self._n(i, "w1")), u, L.EPI_GELU, bias=b1, out1=a, drop=self._drop(i, 1, seed, training))
+                ops.gemm_nt(a, st.w(self._n(i, "w2")), xout, L.EPI_RESID, bias=b2, aux=xmid, drop=self._drop(i, 2, seed, training))
             if save:
                 rec["blocks"].append(dict(xin=cur, h1=h1, mean1=mean1, rstd1=rstd1, qkv=qkv, att=att, lse=lse, xmid=xmid,
                                           h2=h2, mean2=mean2, rstd2=rstd2, u=u, a=a))

@@ -6,10 +6,11 @@ import ctypes as C
 import torch
 
 from . import _lib as L
-from ._lib import Dropout, Embed, Gemm, call
+from ._lib import Dropout, Embed, Fp8Gemm, Gemm, call
 
 BF16 = torch.bfloat16
 F32 = torch.float32
+FP8 = torch.float8_e4m3fn      # OCP e4m3fn: what gfx950's conversion and MFMA instructions implement
 
 
 def _stream():
@@ -82,6 +83,21 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps=1e-5):
     _prof_end(ev, "ln_fwd", 0.0, rows * (6 * cols + 8))          # x fp32 in, y bf16 out, mean / rstd
 
 
+def layernorm_fwd_fp8(x, gamma, beta, y, y8, mean, rstd, eps=1e-5):
+    """LayerNorm forward that also writes the e4m3 image `y8` of its output (fp8 operand path)."""
+    rows, cols = x.shape
+    ev = _prof_begin()
+    call("vitssl_layernorm_fwd_fp8", _chk(x, F32, "x"), _chk(gamma, F32, "gamma", (cols,)), _chk(beta, F32, "beta", (cols,)),
+         _chk(y, BF16, "y", (rows, cols)), _chk(y8, FP8, "y8", (rows, cols)), _chk(mean, F32, "mean", (rows,)),
+         _chk(rstd, F32, "rstd", (rows,)), rows, cols, float(eps), _stream())
+    _prof_end(ev, "ln_fwd", 0.0, rows * (7 * cols + 8))
+
+
+def quantize_fp8(x, y8):
+    """y8 = e4m3(clamp(x, +-448)) of a bf16 tensor (unit scale)."""
+    call("vitssl_quantize_fp8", _chk(x, BF16, "x"), _chk(y8, FP8, "y8", x.shape), x.numel(), _stream())
+
+
 def layernorm_bwd(dy, x, mean, rstd, gamma, g_res, g_out, gm, dgamma, dbeta, gm_colsum=None, drop=NO_DROP):
     rows, cols = x.shape
     ev = _prof_begin()
@@ -139,6 +155,41 @@ def gemm_nt(A, B, out0, epilogue, bias=None, aux=None, out1=None, colsum=None, d
     ev = _prof_begin()
     call("vitssl_gemm_bf16_nt", C.byref(g), _stream())
     _prof_end(ev, f"gemm_nt[epi{epilogue}] {M}x{N}x{K}", 2.0 * M * N * K)
+
+
+def gemm_fp8_nt(A8, B8, out0, epilogue, alpha=None, bias=None, aux=None, out1=None, out_fp8=None, drop=NO_DROP):
+    """out = alpha * (A8[M,K] @ B8[N,K]^T) with the fused epilogue; A8 / B8 are e4m3 operands, `alpha` a device
+    scalar (fp32 tensor with one element: the product of the dequantisation scales), `out_fp8` the optional e4m3
+    image of out1 (EPI_GELU).  Forward GEMMs only (include/vitssl_hip.h)."""
+    M, K = A8.shape
+    N, K2 = B8.shape
+    if K != K2:
+        raise L.VitsslError(f"gemm_fp8_nt: K mismatch {K} vs {K2}")
+    if epilogue not in (L.EPI_BF16, L.EPI_F32, L.EPI_GELU, L.EPI_RESID):
+        raise L.VitsslError(f"gemm_fp8_nt: epilogue {epilogue} has no fp8-operand form")
+    g = Gemm()
+    g.A = _chk(A8, FP8, "A8")
+    g.B = _chk(B8, FP8, "B8")
+    g.M, g.N, g.K = M, N, K
+    g.epilogue = epilogue
+    g.bias = _opt(bias, F32, "bias", (N,))
+    g.out0 = _chk(out0, _OUT0_DTYPE[epilogue], "out0", (M, N))
+    if epilogue == L.EPI_RESID:
+        g.aux = _chk(aux, F32, "aux(residual)", (M, N))
+    g.out1 = _opt(out1, BF16, "out1", (M, N))
+    g.drop = drop
+    q = Fp8Gemm()
+    q.alpha = C.c_void_p(0)
+    if alpha is not None:
+        if alpha.numel() != 1:
+            raise L.VitsslError("gemm_fp8_nt: alpha must hold one fp32 element")
+        q.alpha = _chk(alpha, F32, "alpha")
+    q.out_fp8 = _opt(out_fp8, FP8, "out_fp8", (M, N))
+    if out_fp8 is not None and epilogue != L.EPI_GELU:
+        raise L.VitsslError("gemm_fp8_nt: out_fp8 belongs to EPI_GELU")
+    ev = _prof_begin()
+    call("vitssl_gemm_fp8_nt", C.byref(g), C.byref(q), _stream())
+    _prof_end(ev, f"gemm_fp8_nt[epi{epilogue}] {M}x{N}x{K}", 2.0 * M * N * K)
 
 
 _TN_WS = {}
@@ -299,6 +350,40 @@ class CastPlan:
         self.keep = jobs        # the sources must outlive the launch
         call("vitssl_cast_transpose_batch", C.c_void_p(self.jobs_dev.data_ptr()), C.c_void_p(self.starts_dev.data_ptr()),
              self.njobs, self.total, _stream())
+
+
+class Fp8WeightPlan:
+    """Device-resident job table for `vitssl_fp8_quantize_weights` (per-tensor power-of-two scales computed on the
+    device, no host synchronisation): `alpha` holds one dequantisation factor per job."""
+    CHUNK = 4096
+
+    def __init__(self):
+        self.key = None
+        self.jobs_dev = self.starts_dev = self.amax = self.alpha = None
+        self.njobs = self.total = 0
+        self.keep = None
+
+    def run(self, jobs):
+        """jobs: list of (src f32 [..], dst e4m3 same shape)."""
+        import numpy as np
+        key = tuple((s.data_ptr(), d.data_ptr(), s.numel()) for s, d in jobs)
+        if key != self.key:
+            for s, d in jobs:
+                _chk(s, F32, "src"); _chk(d, FP8, "dst", s.shape)
+            dev = jobs[0][0].device
+            rec = np.zeros(len(jobs), dtype=np.dtype([("src", "<u8"), ("dst", "<u8"), ("n", "<i8")]))
+            starts = np.zeros(len(jobs) + 1, dtype=np.int32)
+            for i, k in enumerate(key):
+                rec[i] = k
+                starts[i + 1] = starts[i] + (k[2] + self.CHUNK - 1) // self.CHUNK
+            self.jobs_dev = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
+            self.starts_dev = torch.from_numpy(starts).to(dev)
+            self.amax = torch.zeros(len(jobs), dtype=F32, device=dev)
+            self.alpha = torch.ones(len(jobs), dtype=F32, device=dev)
+            self.njobs, self.total, self.key = len(jobs), int(starts[-1]), key
+        self.keep = jobs
+        call("vitssl_fp8_quantize_weights", C.c_void_p(self.jobs_dev.data_ptr()), C.c_void_p(self.starts_dev.data_ptr()),
+             self.njobs, self.total, C.c_void_p(self.amax.data_ptr()), C.c_void_p(self.alpha.data_ptr()), _stream())
 
 
 def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step, gscale=1.0):
