@@ -32,6 +32,7 @@ MODELS = {  # standard ViT families
     "vit_l": dict(D=1024, L=24, H=16, F=4096),
 }
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md
+PEAK_FP8_TFLOPS = 5000.0   # dense fp8 MFMA peak (K = 128 f8f6f4 form), MI355X_MICROARCH.md
 PEAK_HBM_TBS = 8.0         # HBM3E spec (6.29 TB/s measured copy ceiling), MI355X_MICROARCH.md
 
 
@@ -132,6 +133,9 @@ def main():
     ap.add_argument("--patch", type=int, default=16)
     ap.add_argument("--mask-ratio", type=float, default=0.6)
     ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
+                    help="operand type of the FORWARD Linear GEMMs of the encoder blocks (fp8 = OCP e4m3, BASELINE configs[4]; "
+                         "backward GEMMs, attention and everything else stay bf16).  The headline metric is bf16.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path on one GPU)")
@@ -154,8 +158,10 @@ def main():
 
     from vit_core.ssl.simmim import SimMIMViT
     from vitssl_hip import ops
+    from vitssl_hip import engine
     from vitssl_hip.engine import GradReducer
     from vitssl_hip.optim import FusedAdamW
+    engine.set_linear_operands(args.dtype)
 
     cfg = MODELS[args.model]
     # The CPU baseline runs FIRST (rank 0, N = 1): the GPU phase then ends the process, where the
@@ -272,15 +278,19 @@ def main():
         dom = max(fam.items(), key=lambda kv: kv[1][1])
         name, (fl, ms, cnt) = dom
         ach = fl / (ms * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic_per_launch(name) if args.model == "vit_b" and args.batch == 256 else (None, None)
-        roofline = {"kernel": {"gemm_nt": "gemm_nt_pp_kernel", "gemm_tn": "gemm_tn_pp_kernel"}.get(name, name + "_kernel"), "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+        traffic, traffic_src = (pmc_traffic_per_launch(name) if args.model == "vit_b" and args.batch == 256 and args.dtype == "bf16"
+                                else (None, None))
+        peak_of = lambda k: PEAK_FP8_TFLOPS if k == "gemm_fp8_nt" else PEAK_BF16_TFLOPS  # noqa: E731
+        roofline = {"kernel": {"gemm_nt": "gemm_nt_pp_kernel", "gemm_tn": "gemm_tn_pp_kernel",
+                               "gemm_fp8_nt": "gemm_nt_pp_kernel<.., fp8>"}.get(name, name + "_kernel"),
+                    "bound": "mfma", "achieved": round(ach, 1), "peak": peak_of(name),
+                    "unit": "TFLOP/s", "frac": round(ach / peak_of(name), 4),
                     "traffic": None if traffic is None else round(traffic), "traffic_unit": "bytes/launch (HBM, PMC)",
                     "traffic_source": traffic_src,
                     "launches_per_step": cnt, "avg_launch_ms": round(ms / cnt, 4),
                     "alg_flops_per_launch": fl / cnt,
-                    "families": {k: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1), "ms_per_step": round(v[1], 3), "launches": v[2]}
-                                 for k, v in fam.items()},
+                    "families": {k: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1), "ms_per_step": round(v[1], 3), "launches": v[2],
+                                     "peak": peak_of(k)} for k, v in fam.items()},
                     "hbm": {k: {"achieved_tbs": round(v[0] / (v[1] * 1e-3) / 1e12, 2), "peak_tbs": PEAK_HBM_TBS,
                                 "frac": round(v[0] / (v[1] * 1e-3) / 1e12 / PEAK_HBM_TBS, 3), "ms_per_step": round(v[1], 3),
                                 "launches": v[2], "alg_bytes_per_launch": round(v[0] / v[2])} for k, v in hbm.items()}}
@@ -289,9 +299,11 @@ def main():
         out = {
             "metric": "images_per_sec", "value": round(imgs_per_s, 2), "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "fp8 e4m3 forward Linear operands, bf16 elsewhere",
+            "data": "synthetic",
             "config": {"workload": f"{args.model.replace('_', '-').upper().replace('VIT-', 'ViT-')}/{args.patch} SimMIM {args.img}x{args.img} "
-                                   f"mask {args.mask_ratio} dropout {args.dropout} AdamW, batch {args.batch}/GPU",
+                                   f"mask {args.mask_ratio} dropout {args.dropout} AdamW, batch {args.batch}/GPU"
+                                   + (", fp8 weight path (forward)" if args.dtype == "fp8" else ""),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}"},
             "per_gpu_images_per_sec": round(imgs_per_s / world, 2),
             "mfma_util": round(step_tflops / PEAK_BF16_TFLOPS, 4),

@@ -181,8 +181,8 @@ def mha(x: Tensor, sd: SD, pre: str, num_heads: int, emu=None, return_attn=False
     v = v.view(B, N, num_heads, dh).transpose(1, 2)
     o, p = sdpa(q, k, v, "bf16" if emu == "fp8" else emu)
     if emu == "fp8":
-        # the attention kernel stores bf16; its e4m3 image is made from that store
-        out = linear_fp8(o.transpose(1, 2).reshape(B, N, D), sd[pre + "final_linear.weight"], None, via_bf16=True)
+        # the attention kernel writes its bf16 and e4m3 images from the same fp32 values
+        out = linear_fp8(o.transpose(1, 2).reshape(B, N, D), sd[pre + "final_linear.weight"], None)
     else:
         o = rnd(o, emu).transpose(1, 2).reshape(B, N, D)
         out = linear(o, sd[pre + "final_linear.weight"], None, emu)

@@ -198,7 +198,7 @@ __device__ __forceinline__ void softmax_tile(f32x4 (&s)[NKT], float& m_out, floa
 template <int NS, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                           float* __restrict__ lse, float* __restrict__ probs, int N, int H,
-                                                          int stagger_wgs, int stagger_ticks) {
+                                                          int stagger_wgs, int stagger_ticks, unsigned char* __restrict__ out8) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int Np = 32 * NS;
   constexpr int NKT = 2 * NS;
@@ -316,6 +316,14 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const bf16_t* __re
         for (int pr = 0; pr < 2; ++pr)
           store_row_pair16(og, pr, g, pack4((t == 0 ? o0[2 * pr] : o1[2 * pr]) * inv[t]),
                            pack4((t == 0 ? o0[2 * pr + 1] : o1[2 * pr + 1]) * inv[t]));
+        if (out8) {   // e4m3 image of the same fp32 values (operand of the fp8 out-projection GEMM)
+          unsigned char* o8 = out8 + ((long long)b * N + q[t]) * (H * DH) + h * DH + 4 * g;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            const f32x4 v = (t == 0 ? o0[dt] : o1[dt]) * inv[t];
+            *(unsigned*)(o8 + 16 * dt) = pack_fp8x4(v[0], v[1], v[2], v[3]);
+          }
+        }
       }
     }
     if (it == 0) ATTN_STAMP(2);
@@ -805,14 +813,15 @@ int ensure_lds(K kernel, int bytes, bool* done, const char* who) {
 }
 
 template <int NS>
-int launch_fwd(const bf16_t* qkv, bf16_t* out, float* lse, float* probs, int B, int N, int H, hipStream_t s) {
+int launch_fwd(const bf16_t* qkv, bf16_t* out, float* lse, float* probs, int B, int N, int H, hipStream_t s,
+               unsigned char* out8 = nullptr) {
   static bool done = false;
   const int lds = 2 * NS * 32 * ROWB;
   constexpr int NW = NS <= 2 ? 2 : 4;
   if (int rc = ensure_lds(attn_fwd_kernel<NS, NW>, lds, &done, "attn_fwd")) return rc;
   const int per_cu = lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3);
   hipLaunchKernelGGL((attn_fwd_kernel<NS, NW>), dim3(B * H), dim3(64 * NW), lds, s, qkv, out, lse, probs, N, H,
-                     attn_cu_count() * per_cu, B * H > 2 * attn_cu_count() * per_cu ? attn_stagger_ticks(0) : 0);
+                     attn_cu_count() * per_cu, B * H > 2 * attn_cu_count() * per_cu ? attn_stagger_ticks(0) : 0, out8);
   VS_CHECK_LAUNCH("attn_fwd");
   return VITSSL_OK;
 }
@@ -886,6 +895,15 @@ extern "C" int vitssl_attn_fwd(const void* qkv, void* out, float* lse, float* pr
   VS_CHECK_ARG(qkv && out && lse, "attn_fwd: null pointer");
   if (int rc = check_attn_shape("attn_fwd", B, N, H, dh)) return rc;
 #define VS_CALL(NS) launch_fwd<NS>((const bf16_t*)qkv, (bf16_t*)out, lse, probs, B, N, H, (hipStream_t)stream)
+  VS_NS_SWITCH((N + 31) / 32, VS_CALL)
+#undef VS_CALL
+}
+
+extern "C" int vitssl_attn_fwd_fp8(const void* qkv, void* out, void* out_fp8, float* lse, float* probs, int B, int N, int H,
+                                   int dh, void* stream) {
+  VS_CHECK_ARG(qkv && out && out_fp8 && lse, "attn_fwd_fp8: null pointer");
+  if (int rc = check_attn_shape("attn_fwd_fp8", B, N, H, dh)) return rc;
+#define VS_CALL(NS) launch_fwd<NS>((const bf16_t*)qkv, (bf16_t*)out, lse, probs, B, N, H, (hipStream_t)stream, (unsigned char*)out_fp8)
   VS_NS_SWITCH((N + 31) / 32, VS_CALL)
 #undef VS_CALL
 }

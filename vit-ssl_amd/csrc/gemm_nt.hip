@@ -469,11 +469,23 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
       if constexpr (EPI == VITSSL_EPI_GELU) store_bf16_row(rsOut1, i, out_b, IC<BF16_AUX>{});
       if constexpr (Q8 && EPI == VITSSL_EPI_GELU) {
         if (q8) {
+          if ((p.N & 15) == 0) {
+            // The row's 64 bytes: dword t*4 + g lives in lane row g as out_q of tile t.  A 4x4 transpose over the
+            // four lane rows (permlane32_swap exchanges the wave halves, permlane16_swap odd / even rows) leaves
+            // lane row g with dwords 4g .. 4g+3 = 16 contiguous bytes: one store instruction per row tile.
+            auto s02 = __builtin_amdgcn_permlane32_swap(out_q[0][0], out_q[1][0], false, false);
+            auto s13 = __builtin_amdgcn_permlane32_swap(out_q[0][1], out_q[1][1], false, false);
+            auto e = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+            auto f = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+            const int n = n0 + wn * 64 + 16 * g4;
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{e[0], e[1], f[0], f[1]}, rsOut2, off_elem(i, n, 1u), 0, BF16_AUX);
+          } else {
 #pragma unroll
-          for (int jp = 0; jp < 2; ++jp)
+            for (int jp = 0; jp < 2; ++jp)
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
-              __builtin_amdgcn_raw_buffer_store_b32(out_q[jp][h], rsOut2, off_elem(i, nn[jp][h], 1u), 0, BF16_AUX);
+              for (int h = 0; h < 2; ++h)
+                __builtin_amdgcn_raw_buffer_store_b32(out_q[jp][h], rsOut2, off_elem(i, nn[jp][h], 1u), 0, BF16_AUX);
+          }
         }
       }
     }

@@ -47,6 +47,7 @@ PROTOTYPES = {
     "vitssl_gemm_bf16_tn": [_vp, _vp, _vp, _i64, _i, _i, _vp, _i64, _vp],
     "vitssl_gemm_fp8_nt": [C.POINTER(Gemm), C.POINTER(Fp8Gemm), _vp],
     "vitssl_quantize_fp8": [_vp, _vp, _i64, _vp],
+    "vitssl_attn_fwd_fp8": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "vitssl_layernorm_fwd_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _vp],
     "vitssl_fp8_quantize_weights": [_vp, _vp, _i, _i, _vp, _vp, _vp],
     "vitssl_attn_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],

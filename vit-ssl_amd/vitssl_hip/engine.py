@@ -400,8 +400,7 @@ class EncoderStack:
                 (wq, aq), (wo, ao), (w1, a1), (w2, a2) = (st.w8(self._n(i, k)) for k in ("wqkv", "wo", "w1", "w2"))
                 ops.layernorm_fwd_fp8(*ln1, h1, x8, mean1, rstd1)
                 ops.gemm_fp8_nt(x8, wq, qkv, L.EPI_BF16, alpha=aq)
-                ops.attn_fwd(qkv, att, lse, B, T, H, dh, probs=probs if i == self.L - 1 else None)
-                ops.quantize_fp8(att, x8)
+                ops.attn_fwd(qkv, att, lse, B, T, H, dh, probs=probs if i == self.L - 1 else None, out_fp8=x8)
                 ops.gemm_fp8_nt(x8, wo, xmid, L.EPI_RESID, alpha=ao, aux=cur, drop=self._drop(i, 0, seed, training))
                 ops.layernorm_fwd_fp8(*ln2, h2, x8, mean2, rstd2)
                 ops.gemm_fp8_nt(x8, w1, u, L.EPI_GELU, alpha=a1, bias=b1, out1=a, out_fp8=a8, drop=self._drop(i, 1, seed, training))

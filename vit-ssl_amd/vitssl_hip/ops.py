@@ -225,13 +225,18 @@ def gemm_tn(A, B, Cacc, atomic=False):
     _prof_end(ev, f"gemm_tn {N1}x{N2}x{M}", 2.0 * M * N1 * N2)
 
 
-def attn_fwd(qkv, out, lse, B, N, H, dh, probs=None):
+def attn_fwd(qkv, out, lse, B, N, H, dh, probs=None, out_fp8=None):
     ev = _prof_begin()
-    _attn_fwd(qkv, out, lse, B, N, H, dh, probs)
+    _attn_fwd(qkv, out, lse, B, N, H, dh, probs, out_fp8)
     _prof_end(ev, f"attn_fwd B{B} N{N} H{H}", 4.0 * B * H * N * N * dh)
 
 
-def _attn_fwd(qkv, out, lse, B, N, H, dh, probs=None):
+def _attn_fwd(qkv, out, lse, B, N, H, dh, probs=None, out_fp8=None):
+    if out_fp8 is not None:       # fp8 operand path: also the e4m3 image of `out`
+        call("vitssl_attn_fwd_fp8", _chk(qkv, BF16, "qkv", (B * N, 3 * H * dh)), _chk(out, BF16, "out", (B * N, H * dh)),
+             _chk(out_fp8, FP8, "out_fp8", (B * N, H * dh)), _chk(lse, F32, "lse", (B, H, N)),
+             _opt(probs, F32, "probs", (B, H, N, N)), B, N, H, dh, _stream())
+        return
     call("vitssl_attn_fwd", _chk(qkv, BF16, "qkv", (B * N, 3 * H * dh)), _chk(out, BF16, "out", (B * N, H * dh)),
          _chk(lse, F32, "lse", (B, H, N)), _opt(probs, F32, "probs", (B, H, N, N)), B, N, H, dh, _stream())
 
