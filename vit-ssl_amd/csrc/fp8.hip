@@ -61,7 +61,10 @@ __global__ __launch_bounds__(Q_THREADS) void fp8_weight_amax_kernel(const vitssl
   __syncthreads();
   if (threadIdx.x == 0) {
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    atomicMax((unsigned*)amax + j, __float_as_uint(m));
+    // same-address atomics serialise in L2 (~5 ns each; a 4 M-element weight is 1024 workgroups): skip the atomic when
+    // the value already there is not smaller.  The plain read may be stale (smaller): then the atomic is merely redundant.
+    unsigned* slot = (unsigned*)amax + j;
+    if (__float_as_uint(m) > __builtin_nontemporal_load(slot)) atomicMax(slot, __float_as_uint(m));
   }
 }
 

@@ -21,6 +21,14 @@ constexpr int LN_THREADS = 256;  // 4 waves = 4 rows in flight per block
 #ifndef LN_HOIST_GRES
 #define LN_HOIST_GRES 1
 #endif
+// 1: backward requests the NEXT row's dy / x / residual gradient before it reduces the current row (the loads fly
+// under the two wave reductions and the stores); costs 7.5 V registers per lane
+#ifndef LN_PREFETCH
+#define LN_PREFETCH 1
+#endif
+#ifndef LN_FWD_PREFETCH
+#define LN_FWD_PREFETCH 1
+#endif
 // 1: forward stores 16 bytes per lane (adjacent lanes trade their v = 0 / v = 1 pieces with a DPP quad
 // swap, so an even lane writes 8 consecutive columns of the first 256, an odd lane of the second 256)
 #ifndef LN_FWD_PAIR
@@ -46,7 +54,18 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restr
     }
   }
   const float inv = 1.0f / (float)cols;
-  for (long long row = (long long)blockIdx.x * 4 + wave; row < rows; row += (long long)gridDim.x * 4) {
+  const long long row_step = (long long)gridDim.x * 4;
+  f32x4 nxt[V];
+  auto fetch = [&](long long row) {
+    if (!LN_FWD_PREFETCH || row >= rows) return;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const int c4 = lane + 64 * v;
+      if (c4 < c4n) nxt[v] = *(const f32x4*)(x + row * cols + 4 * c4);
+    }
+  };
+  fetch((long long)blockIdx.x * 4 + wave);
+  for (long long row = (long long)blockIdx.x * 4 + wave; row < rows; row += row_step) {
     const float* xr = x + row * cols;
     f32x4 xv[V];
     float s = 0.f;
@@ -54,10 +73,11 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restr
     for (int v = 0; v < V; ++v) {
       const int c4 = lane + 64 * v;
       if (c4 < c4n) {
-        xv[v] = *(const f32x4*)(xr + 4 * c4);
+        xv[v] = LN_FWD_PREFETCH ? nxt[v] : *(const f32x4*)(xr + 4 * c4);
         s += xv[v][0] + xv[v][1] + xv[v][2] + xv[v][3];
       }
     }
+    fetch(row + row_step);                        // the next row's load flies under the reductions and the stores
     const float mu = wave_sum(s) * inv;
     float ss = 0.f;
 #pragma unroll
@@ -106,9 +126,17 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restr
   }
 }
 
+// workgroups per CU the register budget is sized for.  The prefetching form holds two rows of operands; where that
+// spills, fewer resident waves win (MI355X, interleaved A/B, M = 50176, D = 768: with column sums + dropout
+// 134 us without prefetch, 154 at 3 workgroups (spills), 125 at 2; without column sums 132 -> 118 at 3)
+constexpr int ln_bwd_blocks(int V, bool has_ln, bool has_cs) {
+  if (!(LN_PREFETCH && has_ln)) return (V <= 2 || (V == 3 && !has_cs)) ? 4 : (V <= 4 ? 3 : 1);
+  return V <= 1 ? 4 : (V == 2 ? (has_cs ? 3 : 4) : (V == 3 ? (has_cs ? 2 : 3) : (V == 4 ? 2 : 1)));
+}
+
 // HAS_LN = false turns the kernel into the plain "mask + cast + column-sum" of g_res.
 template <int V, bool HAS_LN, bool HAS_CS>
-__global__ __launch_bounds__(LN_THREADS, (V <= 2 || (V == 3 && !HAS_CS)) ? 4 : (V <= 4 ? 3 : 1)) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
+__global__ __launch_bounds__(LN_THREADS, ln_bwd_blocks(V, HAS_LN, HAS_CS)) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* g_res,
                                                             float* g_out, bf16_t* __restrict__ gm, float* __restrict__ dgamma,
@@ -128,9 +156,67 @@ __global__ __launch_bounds__(LN_THREADS, (V <= 2 || (V == 3 && !HAS_CS)) ? 4 : (
     if (HAS_LN && c4 < c4n) g[v] = *(const f32x4*)(gamma + 4 * c4);
   }
   const float inv = 1.0f / (float)cols;
-  for (long long row = (long long)blockIdx.x * 4 + wave; row < rows; row += (long long)gridDim.x * 4) {
+  // raw operands of one row (HAS_LN): x, residual gradient, packed dy, statistics
+  f32x4 nx[V], ngr[V];
+  u32x2 ndy[V];
+  float nmu = 0.f, nrs = 0.f;
+  auto fetch = [&](long long row) {
+    if (!(HAS_LN && LN_PREFETCH) || row >= rows) return;
+    nmu = mean[row];
+    nrs = rstd[row];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const int c4 = lane + 64 * v;
+      if (c4 < c4n) {
+        if (g_res) ngr[v] = *(const f32x4*)(g_res + row * cols + 4 * c4);
+        ndy[v] = *(const u32x2*)(dy + row * cols + 4 * c4);
+        nx[v] = *(const f32x4*)(x + row * cols + 4 * c4);
+      }
+    }
+  };
+  const long long row_step = (long long)gridDim.x * 4;
+  fetch((long long)blockIdx.x * 4 + wave);
+  for (long long row = (long long)blockIdx.x * 4 + wave; row < rows; row += row_step) {
     f32x4 dx[V];
-    if constexpr (HAS_LN) {
+    if constexpr (HAS_LN && LN_PREFETCH) {
+      const float mu = nmu, rs = nrs;
+      f32x4 xh[V], gr[V];
+      u32x2 dyp[V];
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        xh[v] = nx[v];
+        gr[v] = ngr[v];
+        dyp[v] = ndy[v];
+      }
+      fetch(row + row_step);                      // in flight during everything below
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const int c4 = lane + 64 * v;
+        if (c4 < c4n) {
+          const f32x4 d = {bf_lo(dyp[v][0]), bf_hi(dyp[v][0]), bf_lo(dyp[v][1]), bf_hi(dyp[v][1])};
+          xh[v] = (xh[v] - mu) * rs;
+          const f32x4 dyg = d * g[v];
+          acc_dg[v] += d * xh[v];
+          acc_db[v] += d;
+          s1 += dyg[0] + dyg[1] + dyg[2] + dyg[3];
+          const f32x4 t = dyg * xh[v];
+          s2 += t[0] + t[1] + t[2] + t[3];
+        }
+      }
+      const float m1 = wave_sum(s1) * inv;
+      const float m2 = wave_sum(s2) * inv;
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const int c4 = lane + 64 * v;
+        if (c4 < c4n) {
+          const f32x4 d = {bf_lo(dyp[v][0]), bf_hi(dyp[v][0]), bf_lo(dyp[v][1]), bf_hi(dyp[v][1])};
+          dx[v] = (d * g[v] - m1 - xh[v] * m2) * rs;
+          if (g_res) dx[v] += gr[v];
+          *(f32x4*)(g_out + row * cols + 4 * c4) = dx[v];
+        }
+      }
+    } else if constexpr (HAS_LN) {
       const float mu = mean[row], rs = rstd[row];
       f32x4 xh[V];
       f32x4 gr[V];
