@@ -121,12 +121,16 @@ int vitssl_gemm_bf16_nt(const vitssl_gemm_t* g, void* stream);
  * "ViT-L/16 SimMIM, fp8 MFMA weight path" (the same nn.Linear call sites as above:
  * vit_core/attention.py:54-58,105; feed_forward.py:14-15,26-28).  Same contraction, epilogues and
  * output types as vitssl_gemm_bf16_nt, but A [M,K] and B [N,K] are e4m3 bytes, K % 128 == 0, and the
- * MFMA is v_mfma_f32_16x16x128_f8f6f4 (fp32 accumulate).  Epilogues BF16 / F32 / GELU / RESID; the
- * backward GEMMs keep bf16 operands. */
+ * MFMA is v_mfma_f32_16x16x128_f8f6f4 (fp32 accumulate).  Epilogues BF16 / F32 / GELU / RESID / DGELU: the
+ * forward products and the input-gradient products dX = dY . W (dY quantised with a per-tensor scale that
+ * follows the previous step's max |dY|); the weight-gradient GEMM keeps bf16 operands. */
 typedef struct {
-  const float* alpha; /* device scalar: acc is multiplied by *alpha before the epilogue (product of the
-                         operands' dequantisation scales; vitssl_fp8_quantize_weights writes it), or NULL = 1 */
-  void* out_fp8;      /* EPI_GELU only: e4m3 [M,N] image of out1 (the A operand of the next fp8 GEMM), or NULL */
+  const float* alpha;  /* device scalar: acc is multiplied by *alpha before the epilogue (dequantisation scale of the
+                          weight operand; vitssl_fp8_quantize_weights writes it), or NULL = 1 */
+  const float* alpha2; /* second device scalar multiplied in (1 / scale of a scaled gradient operand), or NULL = 1 */
+  void* out_fp8;       /* EPI_GELU: e4m3 [M,N] image of out1; EPI_DGELU: of out0 (the A operand of the next fp8 GEMM); or NULL */
+  const float* out_scale; /* device scalar the values are multiplied by before quantisation into out_fp8, or NULL = 1 */
+  float* out_amax;     /* device slot: atomic max of |value| written to out_fp8 (before scaling; caller zeroes), or NULL */
 } vitssl_fp8_gemm_t;
 int vitssl_gemm_fp8_nt(const vitssl_gemm_t* g, const vitssl_fp8_gemm_t* q, void* stream);
 
@@ -135,20 +139,32 @@ int vitssl_attn_fwd_fp8(const void* qkv, void* out, void* out_fp8, float* lse, f
                         void* stream);
 /* y_fp8[n] = e4m3(clamp(x, -448, 448)), round to nearest even (activations are quantised at unit scale) */
 int vitssl_quantize_fp8(const void* x_bf16, void* y_fp8, int64_t n, void* stream);
+/* y_fp8[n] = e4m3(x * *qscale) (qscale NULL = 1); *qamax = max(*qamax, max|x|) (NULL = not recorded; caller zeroes) */
+int vitssl_quantize_fp8_scaled(const void* x_bf16, void* y_fp8, int64_t n, const float* qscale, float* qamax, void* stream);
 /* LayerNorm forward that also emits the e4m3 image of its output (operand of the next fp8 GEMM);
  * y_bf16 is still written: the weight-gradient GEMM of the backward pass reads it. */
 int vitssl_layernorm_fwd_fp8(const float* x, const float* gamma, const float* beta, void* y_bf16, void* y_fp8,
                              float* mean, float* rstd, int64_t rows, int cols, float eps, void* stream);
+/* vitssl_layernorm_bwd / vitssl_grad_mask_cast that also write gm_fp8 = e4m3(gm * *qscale) and record max|gm| in
+ * *qamax: the scaled e4m3 operand of the fp8 input-gradient GEMM that consumes gm (gm_bf16 stays: wgrad reads it) */
+int vitssl_layernorm_bwd_fp8(const void* dy_bf16, const float* x, const float* mean, const float* rstd, const float* gamma,
+                             const float* g_res, float* g_out, void* gm_bf16, void* gm_fp8, const float* qscale, float* qamax,
+                             float* dgamma, float* dbeta, float* gm_colsum, vitssl_dropout_t drop, int64_t rows, int cols,
+                             void* stream);
+int vitssl_grad_mask_cast_fp8(const float* g, void* gm_bf16, void* gm_fp8, const float* qscale, float* qamax, float* gm_colsum,
+                              vitssl_dropout_t drop, int64_t rows, int cols, void* stream);
 /* Per-step fp8 refresh of a table of weights in one call (three launches): per tensor j,
  * amax_j = max|src|, k_j = floor(log2(448 / amax_j)) (0 when amax_j = 0; a power-of-two scale is exact),
- * dst_fp8 = e4m3(src * 2^k_j), alpha[j] = 2^-k_j.  `jobs`, `chunk_start`, `amax_ws` [njobs] and `alpha`
- * [njobs] live in DEVICE memory; chunk_start[njobs + 1] is the exclusive prefix sum of ceil(n / 4096). */
+ * dst_fp8 [R,C] = e4m3(src * 2^k_j) (forward operand), dst_t_fp8 [C,R] = its transpose (input-gradient operand),
+ * alpha[j] = 2^-k_j.  `jobs`, `tile_start`, `amax_ws` [njobs] and `alpha` [njobs] live in DEVICE memory;
+ * tile_start[njobs + 1] is the exclusive prefix sum of ceil(R/64)*ceil(C/64). */
 typedef struct {
-  const float* src; /* f32 [n] */
-  void* dst_fp8;    /* e4m3 [n] */
-  int64_t n;
+  const float* src; /* f32 [R, C] */
+  void* dst_fp8;    /* e4m3 [R, C] or NULL */
+  void* dst_t_fp8;  /* e4m3 [C, R] or NULL */
+  int R, C;
 } vitssl_fp8_weight_job_t;
-int vitssl_fp8_quantize_weights(const vitssl_fp8_weight_job_t* jobs, const int* chunk_start, int njobs, int total_chunks,
+int vitssl_fp8_quantize_weights(const vitssl_fp8_weight_job_t* jobs, const int* tile_start, int njobs, int total_tiles,
                                 float* amax_ws, float* alpha, void* stream);
 
 /* Weight gradient: C[N1,N2] (fp32) += A[M,N1]^T . B[M,N2]  (contraction over rows).

@@ -18,8 +18,9 @@ Two modes:
     run their FORWARD product on OCP e4m3fn operands (BASELINE configs[4], "fp8
     weight path"): activations quantised at unit scale (saturating at +-448),
     weights per tensor with the power-of-two scale 2^floor(log2(448 / max|w|)),
-    fp32 accumulation; their backward products use the bf16 operands, as the HIP
-    path does.  The reference has no fp8 code: this mode restates the HIP design,
+    fp32 accumulation.  With the gradient scales the HIP engine exports
+    (``fp8_gscales``) the input-gradient products dX = dY.W run on e4m3 operands as
+    well (dY quantised with that per-tensor scale); weight gradients use bf16 operands.  The reference has no fp8 code: this mode restates the HIP design,
     and is tied to the reference only through its fp32 / bf16 siblings.
 
 Pinned against fixtures generated from the reference (tests/golden).
@@ -78,32 +79,39 @@ def fp8_scale_exp(amax: float) -> int:
 
 
 class _LinearFP8(torch.autograd.Function):
-    """y = (q8(x) . q8(w 2^k)^T) 2^-k in the forward; the backward products take bf16(x) and bf16(w)."""
+    """y = (q8(x) . q8(w 2^k)^T) 2^-k in the forward.  Backward: the weight gradient takes bf16(x); the input
+    gradient takes bf16(w), or -- with a gradient scale s (fp8 input-gradient GEMMs) -- q8(g s) . q8(w 2^k) 2^-k / s."""
 
     @staticmethod
-    def forward(ctx, x32, w, k, via_bf16):
+    def forward(ctx, x32, w, k, via_bf16, gscale):
         xb = x32.to(torch.bfloat16).to(torch.float32)
         wb = w.to(torch.bfloat16).to(torch.float32)
         x8 = q8(xb if via_bf16 else x32)
         w8 = q8(w * (2.0 ** k))
-        ctx.save_for_backward(xb, wb)
+        ctx.save_for_backward(xb, wb, w8)
+        ctx.k, ctx.gscale = k, gscale
         return (x8 @ w8.t()) * (2.0 ** -k)
 
     @staticmethod
     def backward(ctx, g):
-        xb, wb = ctx.saved_tensors
-        gx = g @ wb
+        xb, wb, w8 = ctx.saved_tensors
+        if ctx.gscale is None:
+            gx = g @ wb
+        else:
+            gx = (q8(g * ctx.gscale) @ w8) * ((2.0 ** -ctx.k) / ctx.gscale)
         gw = g.reshape(-1, g.shape[-1]).t() @ xb.reshape(-1, xb.shape[-1])
-        return gx, gw, None, None
+        return gx, gw, None, None, None
 
 
-def linear_fp8(x32: Tensor, w: Tensor, b: Optional[Tensor], k: Optional[int] = None, via_bf16: bool = False) -> Tensor:
+def linear_fp8(x32: Tensor, w: Tensor, b: Optional[Tensor], k: Optional[int] = None, via_bf16: bool = False,
+               gscale: Optional[float] = None) -> Tensor:
     """Block Linear on e4m3 operands.  `x32` is the fp32 value the HIP producer holds when it writes its bf16 and
     e4m3 images (via_bf16: the e4m3 image is made from the bf16 one).  `k`: scale exponent of the weight tensor
-    (default: from this tensor's own max; the fused QKV weight shares one)."""
+    (default: from this tensor's own max; the fused QKV weight shares one).  `gscale`: scale the HIP path quantised
+    the gradient of this layer's output with (exported by the engine); None = bf16 input-gradient product."""
     if k is None:
         k = fp8_scale_exp(float(w.detach().abs().max()))
-    y = _LinearFP8.apply(x32, w, k, via_bf16)
+    y = _LinearFP8.apply(x32, w, k, via_bf16, gscale)
     if b is not None:
         y = y + b
     return y
@@ -161,7 +169,7 @@ def sdpa(q: Tensor, k: Tensor, v: Tensor, emu=None) -> Tuple[Tensor, Tensor]:
     return o, p
 
 
-def mha(x: Tensor, sd: SD, pre: str, num_heads: int, emu=None, return_attn=False):
+def mha(x: Tensor, sd: SD, pre: str, num_heads: int, emu=None, return_attn=False, gscales=None):
     """MultiHeadedAttention.forward, self-attention case (vit_core/attention.py:78-106).
     Three bias-free projections, head split, SDPA, merge, bias-free final_linear."""
     B, N, D = x.shape
@@ -169,9 +177,10 @@ def mha(x: Tensor, sd: SD, pre: str, num_heads: int, emu=None, return_attn=False
     if emu == "fp8":
         # x is the un-rounded LayerNorm output; the HIP path multiplies by ONE fused [3D, D] weight image
         kq = fp8_scale_exp(max(float(sd[pre + n].detach().abs().max()) for n in ("w_query.weight", "w_key.weight", "w_value.weight")))
-        q = rnd(linear_fp8(x, sd[pre + "w_query.weight"], None, kq), emu)
-        k = rnd(linear_fp8(x, sd[pre + "w_key.weight"], None, kq), emu)
-        v = rnd(linear_fp8(x, sd[pre + "w_value.weight"], None, kq), emu)
+        gq = None if gscales is None else float(gscales[3])      # one scale for the fused dQKV tensor
+        q = rnd(linear_fp8(x, sd[pre + "w_query.weight"], None, kq, gscale=gq), emu)
+        k = rnd(linear_fp8(x, sd[pre + "w_key.weight"], None, kq, gscale=gq), emu)
+        v = rnd(linear_fp8(x, sd[pre + "w_value.weight"], None, kq, gscale=gq), emu)
     else:
         q = rnd(linear(x, sd[pre + "w_query.weight"], None, emu), emu)
         k = rnd(linear(x, sd[pre + "w_key.weight"], None, emu), emu)
@@ -182,7 +191,8 @@ def mha(x: Tensor, sd: SD, pre: str, num_heads: int, emu=None, return_attn=False
     o, p = sdpa(q, k, v, "bf16" if emu == "fp8" else emu)
     if emu == "fp8":
         # the attention kernel writes its bf16 and e4m3 images from the same fp32 values
-        out = linear_fp8(o.transpose(1, 2).reshape(B, N, D), sd[pre + "final_linear.weight"], None)
+        out = linear_fp8(o.transpose(1, 2).reshape(B, N, D), sd[pre + "final_linear.weight"], None,
+                         gscale=None if gscales is None else float(gscales[2]))
     else:
         o = rnd(o, emu).transpose(1, 2).reshape(B, N, D)
         out = linear(o, sd[pre + "final_linear.weight"], None, emu)
@@ -190,39 +200,43 @@ def mha(x: Tensor, sd: SD, pre: str, num_heads: int, emu=None, return_attn=False
 
 
 def feed_forward(x: Tensor, sd: SD, pre: str, emu=None, keep_inner: Optional[Tensor] = None,
-                 p_drop: float = 0.0) -> Tensor:
+                 p_drop: float = 0.0, gscales=None) -> Tensor:
     """FeedForwardBlock.forward (vit_core/feed_forward.py:26-28)."""
     if emu == "fp8":
-        u = rnd(linear_fp8(x, sd[pre + "linear_in.weight"], sd[pre + "linear_in.bias"]), emu)
+        u = rnd(linear_fp8(x, sd[pre + "linear_in.weight"], sd[pre + "linear_in.bias"],
+                           gscale=None if gscales is None else float(gscales[1])), emu)
     else:
         u = rnd(linear(x, sd[pre + "linear_in.weight"], sd[pre + "linear_in.bias"], emu), emu)
     a = gelu_erf(u)
     if keep_inner is not None:
         a = a * keep_inner / (1.0 - p_drop)
     if emu == "fp8":
-        return linear_fp8(a, sd[pre + "linear_out.weight"], sd[pre + "linear_out.bias"])
+        return linear_fp8(a, sd[pre + "linear_out.weight"], sd[pre + "linear_out.bias"],
+                          gscale=None if gscales is None else float(gscales[0]))
     a = rnd(a, emu)
     return linear(a, sd[pre + "linear_out.weight"], sd[pre + "linear_out.bias"], emu)
 
 
 def encoder_block(x: Tensor, sd: SD, pre: str, num_heads: int, emu=None,
                   keep: Optional[Sequence[Tensor]] = None, p_drop: float = 0.0,
-                  return_attn=False):
+                  return_attn=False, fp8_gscales=None):
     """EncoderBlock.forward, Pre-LN (vit_core/encoder_block.py:40-53).
 
     ``keep`` = optional (keep1, keep_inner, keep2) 0/1 masks for the three
-    dropout sites (drop1, FFN inner, drop2); survivors scaled by 1/(1-p)."""
+    dropout sites (drop1, FFN inner, drop2); survivors scaled by 1/(1-p).
+    ``fp8_gscales`` (emu="fp8" only) = the four scales the HIP path quantised this block's gradient operands with
+    (d FFN-out, d FFN-hidden, d attention-out, dQKV): the input-gradient products then run on e4m3 operands too."""
     sc = 1.0 / (1.0 - p_drop) if keep is not None else 1.0
     # (fp8: the Linear layers take the un-rounded LayerNorm output and make both operand images themselves)
     ln_emu = None if emu == "fp8" else emu
     h = rnd(layer_norm(x, sd[pre + "layer_norm1.weight"], sd[pre + "layer_norm1.bias"]), ln_emu)
-    a, probs = mha(h, sd, pre + "self_attention.", num_heads, emu, return_attn)
+    a, probs = mha(h, sd, pre + "self_attention.", num_heads, emu, return_attn, gscales=fp8_gscales)
     if keep is not None:
         a = a * keep[0] * sc
     x = x + a
     h = rnd(layer_norm(x, sd[pre + "layer_norm2.weight"], sd[pre + "layer_norm2.bias"]), ln_emu)
     f = feed_forward(h, sd, pre + "feed_forward.", emu,
-                     keep_inner=None if keep is None else keep[1], p_drop=p_drop)
+                     keep_inner=None if keep is None else keep[1], p_drop=p_drop, gscales=fp8_gscales)
     if keep is not None:
         f = f * keep[2] * sc
     x = x + f
@@ -254,7 +268,7 @@ def simple_masking(batch: int, num_patches: int, mask_ratio: float,
 
 
 def simmim_forward(sd: SD, x: Tensor, mask: Tensor, patch: int, num_heads: int, emu=None,
-                   keeps: Optional[List[Sequence[Tensor]]] = None, p_drop: float = 0.0):
+                   keeps: Optional[List[Sequence[Tensor]]] = None, p_drop: float = 0.0, fp8_gscales=None):
     """SimMIMViT.forward (vit_core/ssl/simmim/model.py:43-62) for a given bool mask.
     Returns (pred [B*nm, Pd], targets [B*nm, Pd]); rows in ascending (b, n) order."""
     patches = patchify(x, patch)
@@ -265,7 +279,8 @@ def simmim_forward(sd: SD, x: Tensor, mask: Tensor, patch: int, num_heads: int, 
     h = tok
     for i in range(num_blocks_of(sd)):
         h, _ = encoder_block(h, sd, f"encoder_blocks.{i}.", num_heads, emu,
-                             keep=None if keeps is None else keeps[i], p_drop=p_drop)
+                             keep=None if keeps is None else keeps[i], p_drop=p_drop,
+                             fp8_gscales=None if fp8_gscales is None else fp8_gscales[i])
     sel = h[mask]
     pred = linear(sel, sd["simmim_head.weight"], sd["simmim_head.bias"], emu)
     return pred, targets

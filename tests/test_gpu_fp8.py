@@ -50,23 +50,86 @@ def test_fp8_weight_images_bit_exact():
     from oracle import vit_oracle as O
     from vitssl_hip import ops
     g = torch.Generator().manual_seed(1)
-    shapes = [(384, 128), (128, 128), (512, 128), (128, 512), (5, 7)]
-    scales = [0.02, 3.0, 448.0 / 4.0, 1e-6, 0.5]
+    shapes = [(384, 128), (128, 128), (512, 128), (128, 512), (5, 7), (70, 130)]
+    scales = [0.02, 3.0, 448.0 / 4.0, 1e-6, 0.5, 10.0]
     srcs = [(torch.randn(*s, generator=g) * sc) for s, sc in zip(shapes, scales)]
     srcs[2][0, 0] = 448.0            # amax exactly on the 0.875 boundary of the exponent rule
     srcs.append(torch.zeros(64, 64))  # all-zero tensor: scale exponent 0
     dev = [s.to(DEV) for s in srcs]
     dst = [torch.empty(s.shape, dtype=FP8, device=DEV) for s in srcs]
+    dst_t = [torch.empty(s.shape[::-1], dtype=FP8, device=DEV) for s in srcs]
+    dst[1] = None                     # only the transposed image / only the plain one
+    dst_t[3] = None
     plan = ops.Fp8WeightPlan()
-    plan.run(list(zip(dev, dst)))
-    plan.run(list(zip(dev, dst)))     # cached job table
+    plan.run(list(zip(dev, dst, dst_t)))
+    plan.run(list(zip(dev, dst, dst_t)))     # cached job table
     alpha = plan.alpha.cpu()
     for i, s in enumerate(srcs):
         k = O.fp8_scale_exp(float(s.abs().max()))
         assert float(alpha[i]) == 2.0 ** -k, (i, float(alpha[i]), k)
         want = _q8_torch(s * (2.0 ** k))
-        assert torch.equal(dst[i].cpu().view(torch.uint8), want.view(torch.uint8)), i
+        if dst[i] is not None:
+            assert torch.equal(dst[i].cpu().view(torch.uint8), want.view(torch.uint8)), i
+        if dst_t[i] is not None:
+            assert torch.equal(dst_t[i].cpu().view(torch.uint8), want.view(torch.uint8).t().contiguous()), i
         assert float(want.float().abs().max()) <= 448.0 and (float(s.abs().max()) == 0 or float(want.float().abs().max()) > 224.0 * 0.9)
+
+
+def test_quantize_fp8_scaled_and_amax():
+    from vitssl_hip import ops
+    torch.manual_seed(2)
+    x = (torch.randn(70001) * 3e-4).to(torch.bfloat16)
+    xd = x.to(DEV)
+    y = torch.empty(x.shape, dtype=FP8, device=DEV)
+    scale = torch.tensor([2.0 ** 17], device=DEV)
+    amax = torch.tensor([1e-5], device=DEV)            # a smaller running maximum is replaced
+    ops.quantize_fp8(xd, y, scale=scale, amax=amax)
+    assert torch.equal(y.cpu().view(torch.uint8), _q8_torch(x.float() * 2.0 ** 17).view(torch.uint8))
+    assert float(amax) == float(x.float().abs().max())
+    big = torch.tensor([1.0], device=DEV)              # a larger one is kept
+    ops.quantize_fp8(xd, y, scale=scale, amax=big)
+    assert float(big) == 1.0
+
+
+def test_layernorm_bwd_fp8_image():
+    from vitssl_hip import ops
+    torch.manual_seed(6)
+    rows, cols = 500, 768
+    x = torch.randn(rows, cols, device=DEV)
+    dy = (torch.randn(rows, cols, device=DEV) * 1e-3).to(torch.bfloat16)
+    gres = torch.randn(rows, cols, device=DEV) * 1e-3
+    gamma = (1 + 0.1 * torch.randn(cols)).to(DEV)
+    mean, rstd = x.mean(1), 1.0 / torch.sqrt(x.var(1, unbiased=False) + 1e-5)
+    drop = ops.make_dropout(0.1, 5, 2)
+    outs = []
+    for fp8 in (False, True):
+        go, gm = torch.empty(rows, cols, device=DEV), torch.empty(rows, cols, dtype=torch.bfloat16, device=DEV)
+        dg, db, cs = (torch.zeros(cols, device=DEV) for _ in range(3))
+        if fp8:
+            gm8 = torch.empty(rows, cols, dtype=FP8, device=DEV)
+            scale, amax = torch.tensor([2.0 ** 14], device=DEV), torch.zeros(1, device=DEV)
+            ops.layernorm_bwd_fp8(dy, x, mean, rstd, gamma, gres, go, gm, gm8, scale, amax, dg, db, cs, drop)
+        else:
+            ops.layernorm_bwd(dy, x, mean, rstd, gamma, gres, go, gm, dg, db, cs, drop)
+        outs.append((go, gm, dg, db, cs))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])   # g_out and gm: the bf16 kernel's result
+    for a, b in zip(outs[0][2:], outs[1][2:]):
+        assert rel_l2(a, b) < 1e-5                                      # column reductions: fp32 atomics, order varies
+    keep = ops.dropout_mask(rows, cols, drop, DEV).float()
+    gm32 = outs[1][0] * keep / 0.9                                      # what the kernel held in fp32
+    assert abs(float(amax) - float(gm32.abs().max())) <= 1e-4 * float(amax)   # the reference is recomputed in another order
+    want = _q8_torch((gm32 * 2.0 ** 14).cpu())
+    same = (gm8.cpu().view(torch.uint8) == want.view(torch.uint8)).float().mean()
+    assert float(same) > 0.999
+    # the standalone mask + cast form
+    g = torch.randn(rows, cols, device=DEV) * 1e-3
+    gm, gm8 = torch.empty(rows, cols, dtype=torch.bfloat16, device=DEV), torch.empty(rows, cols, dtype=FP8, device=DEV)
+    amax.zero_()
+    ops.grad_mask_cast_fp8(g, gm, gm8, scale, amax, None, drop)
+    # (the kernel's survivor scale is 65536 / (65536 - round(p 65536)), not exactly 1 / 0.9: a rounding flips now and then)
+    same = (gm8.cpu().view(torch.uint8) == _q8_torch((g * keep / 0.9 * 2.0 ** 14).cpu()).view(torch.uint8)).float().mean()
+    assert float(same) > 0.999
+    assert abs(float(amax) - float((g * keep / 0.9).abs().max())) <= 1e-4 * float(amax)
 
 
 @pytest.mark.parametrize("cols", [128, 384, 768, 1024])
@@ -172,6 +235,31 @@ def test_gemm_fp8_identity_layout():
     assert torch.equal(out.cpu(), Bm.t().contiguous())
 
 
+@pytest.mark.parametrize("M,N,K", [(600, 512, 256), (1000, 260, 128)])
+def test_gemm_fp8_dgelu_with_scaled_image(M, N, K):
+    """The input-gradient form: dY (e4m3, scaled) . W^T image, dGELU epilogue, column sums, scaled e4m3 image + max|.|."""
+    from vitssl_hip import _lib as L, ops
+    torch.manual_seed(M + N)
+    s_in, s_out = 2.0 ** 12, 2.0 ** 9
+    dY = torch.randn(M, K) * 2e-3
+    A = _q8_torch(dY * s_in).to(DEV)
+    Bw = _q8_torch(torch.randn(N, K) * 100).to(DEV)
+    alpha, alpha2 = torch.tensor([2.0 ** -7], device=DEV), torch.tensor([1.0 / s_in], device=DEV)
+    gp = (torch.rand(M, N) * 1.2).to(torch.bfloat16).to(DEV)
+    ref = (_f32(A) @ _f32(Bw).t()) * (2.0 ** -7 / s_in) * gp.float()
+    du = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    du8 = torch.empty(M, N, dtype=FP8, device=DEV)
+    cs = torch.zeros(N, device=DEV)
+    scale, amax = torch.tensor([s_out], device=DEV), torch.zeros(1, device=DEV)
+    ops.gemm_fp8_nt(A, Bw, du, L.EPI_DGELU, alpha=alpha, alpha2=alpha2, aux=gp, colsum=cs, out_fp8=du8, out_scale=scale, out_amax=amax)
+    assert rel_l2(du, ref) < 4e-3
+    assert rel_l2(cs, ref.sum(0)) < 1e-4
+    assert abs(float(amax) - float(ref.abs().max())) <= 1e-4 * float(amax)
+    assert rel_l2(_f32(du8) / s_out, ref) < 4e-2
+    same = (du8.cpu().view(torch.uint8) == _q8_torch((ref * s_out).cpu()).view(torch.uint8)).float().mean()
+    assert float(same) > 0.99
+
+
 def test_gemm_fp8_rejects_bad_arguments():
     from vitssl_hip import _lib as L, ops
     A = torch.zeros(64, 192, dtype=FP8, device=DEV)
@@ -181,7 +269,9 @@ def test_gemm_fp8_rejects_bad_arguments():
     A = torch.zeros(64, 128, dtype=FP8, device=DEV)
     Bw = torch.zeros(64, 128, dtype=FP8, device=DEV)
     with pytest.raises(L.VitsslError):
-        ops.gemm_fp8_nt(A, Bw, torch.empty(64, 64, dtype=torch.bfloat16, device=DEV), L.EPI_DGELU)
+        ops.gemm_fp8_nt(A, Bw, torch.empty(64, 64, dtype=torch.bfloat16, device=DEV), L.EPI_DGELU)     # needs aux
+    with pytest.raises(L.VitsslError):
+        ops.gemm_fp8_nt(A, Bw, torch.empty(64, 64, device=DEV), L.EPI_EMBED)
     with pytest.raises(L.VitsslError):
         ops.gemm_fp8_nt(A.to(torch.bfloat16), Bw, torch.empty(64, 64, device=DEV), L.EPI_F32)
 
@@ -194,19 +284,32 @@ def test_encoder_block_fp8_matches_oracle(fp8_operands):
     sd = {k: v.detach().clone() for k, v in blk.state_dict().items()}
     blk = blk.to(DEV).train()
     x = torch.randn(3, 20, 128)
-    xd = x.to(DEV).requires_grad_(True)
-    y, _ = blk(xd)
-    y.square().mean().backward()
-    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    xr = x.clone().requires_grad_(True)
-    ry, _ = O.encoder_block(xr, leaves, "", 2, emu="fp8")
-    ry.square().mean().backward()
-    assert rel_l2(y, ry) < 1e-2                      # same quantisation points: the bf16 path's tolerance
-    assert rel_l2(xd.grad, xr.grad) < 5e-2
-    for k, p in blk.named_parameters():
-        assert rel_l2(p.grad, leaves[k].grad) < 5e-2, (k, rel_l2(p.grad, leaves[k].grad))
+    scales = []
+    for step in range(2):      # first backward: scales from the tensors themselves; second: delayed (previous step's max, one bit of headroom)
+        blk.zero_grad(set_to_none=True)
+        xd = x.to(DEV).requires_grad_(True)
+        y, _ = blk(xd)
+        y.square().mean().backward()
+        gs = blk._runner.stack.fp8_grad_scales().cpu()
+        scales.append(gs)
+        leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        xr = x.clone().requires_grad_(True)
+        ry, _ = O.encoder_block(xr, leaves, "", 2, emu="fp8", fp8_gscales=gs[0].tolist())
+        ry.square().mean().backward()
+        assert rel_l2(y, ry) < 1e-2                      # same quantisation points: the bf16 path's tolerance
+        assert rel_l2(xd.grad, xr.grad) < 5e-2
+        for k, p in blk.named_parameters():
+            assert rel_l2(p.grad, leaves[k].grad) < 5e-2, (step, k, rel_l2(p.grad, leaves[k].grad))
+    assert torch.equal(scales[1], scales[0] / 2)         # same gradients, one bit of headroom
+    assert bool((scales[0] > 1.0).all())                  # gradients of a mean-square loss are far below 1: they need the scale
     fy, _ = O.encoder_block(x, sd, "", 2)
     assert 1e-3 < rel_l2(y, fy) < 5e-2               # and against pure fp32: e4m3 operands cost ~1.5 % here (bf16: 0.1 %)
+    # against the fp32 gradients: e4m3 gradient operands add their 2^-4 relative rounding
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    fy, _ = O.encoder_block(x, leaves, "", 2)
+    fy.square().mean().backward()
+    for k, p in blk.named_parameters():
+        assert rel_l2(p.grad, leaves[k].grad) < 0.12, (k, rel_l2(p.grad, leaves[k].grad))
 
 
 def test_simmim_fp8_matches_oracle_and_trains(fp8_operands):
@@ -227,7 +330,7 @@ def test_simmim_fp8_matches_oracle_and_trains(fp8_operands):
     torch.manual_seed(9)
     mask = draw_mask(4, 16, 0.6)
     leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    pe, te = O.simmim_forward(leaves, x, mask, 16, 2, emu="fp8")
+    pe, te = O.simmim_forward(leaves, x, mask, 16, 2, emu="fp8", fp8_gscales=model.runtime().stack.fp8_grad_scales().cpu().tolist())
     assert torch.equal(tgt.cpu(), te) and rel_l2(pred, pe) < 1e-2
     wl = O.l1_loss_mean(pe, te)
     wl.backward()
@@ -262,7 +365,7 @@ def test_vit_l_shaped_blocks_fp8(fp8_operands):
     torch.manual_seed(9)
     mask = draw_mask(2, 196, 0.6)
     leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    pe, te = O.simmim_forward(leaves, x, mask, 16, 16, emu="fp8")
+    pe, te = O.simmim_forward(leaves, x, mask, 16, 16, emu="fp8", fp8_gscales=model.runtime().stack.fp8_grad_scales().cpu().tolist())
     assert torch.equal(tgt.cpu(), te) and rel_l2(pred, pe) < 1e-2
     wl = O.l1_loss_mean(pe, te)
     wl.backward()

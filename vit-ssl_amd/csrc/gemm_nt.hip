@@ -114,7 +114,10 @@ struct NtParams {
   int stagger;   // ping-pong kernel: estimated time of one output tile in 100 MHz ticks (0 = no start-up stagger)
   int esz;       // operand element size in bytes: 2 = bf16, 1 = fp8 e4m3 (ping-pong kernel only)
   const float* alpha;   // fp8 operands: device scalar multiplied into the accumulators (product of the dequantisation scales), or NULL
-  void* out2;    // fp8 operands, EPI_GELU: optional e4m3 image of out1 (the next GEMM's A operand), or NULL
+  void* out2;    // fp8 operands: optional e4m3 image of out1 (EPI_GELU) / of out0 (EPI_DGELU) = the next GEMM's A operand, or NULL
+  const float* alpha2;  // second device scalar multiplied into the accumulators (1 / scale of a scaled gradient operand), or NULL
+  const float* qscale;  // device scalar the values are multiplied by before they are quantised into out2 (NULL = 1)
+  float* qamax;         // device slot that receives max |value| written to out2, before scaling (atomic max; NULL = none)
 #ifdef VITSSL_NT_STAMPS
   unsigned long long* stamps;   // diagnostic build only (tools/nt_stamps.py): [wg][2 wave groups][16 rounds][4] x 100 MHz ticks
 #endif
@@ -283,8 +286,11 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
     }
   };
   __amdgpu_buffer_rsrc_t rsOut0, rsOut1, rsOut2, rsAux;
-  const bool q8 = Q8 && EPI == VITSSL_EPI_GELU && p.out2 != nullptr;
+  constexpr bool Q8EPI = Q8 && (EPI == VITSSL_EPI_GELU || EPI == VITSSL_EPI_DGELU);
+  const bool q8 = Q8EPI && p.out2 != nullptr;
   if (q8) rsOut2 = window(p.out2, 1);
+  const float qs = (Q8EPI && p.qscale) ? *p.qscale : 1.0f;
+  float qmax = 0.f;                               // running max |value| of this lane's share of the e4m3 image
   if constexpr (EPI == VITSSL_EPI_BF16 || EPI == VITSSL_EPI_GELU || EPI == VITSSL_EPI_DGELU) rsOut0 = window(p.out0, 2);
   if constexpr (EPI == VITSSL_EPI_F32 || EPI == VITSSL_EPI_RESID) rsOut0 = window(p.out0, 4);
   if constexpr (EPI == VITSSL_EPI_GELU) rsOut1 = window(p.out1, 2);
@@ -407,7 +413,10 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
             }
             out_b[jp][h] = u32x2{pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
             out_a[jp][h] = u32x2{pack_bf2(d[0], d[1]), pack_bf2(d[2], d[3])};
-            if constexpr (Q8) out_q[jp][h] = pack_fp8x4(y[0], y[1], y[2], y[3]);
+            if constexpr (Q8) {
+              out_q[jp][h] = pack_fp8x4(y[0] * qs, y[1] * qs, y[2] * qs, y[3] * qs);
+              if (okm && okn[jp][h]) qmax = fmaxf(qmax, fmaxf(fmaxf(fabsf(y[0]), fabsf(y[1])), fmaxf(fabsf(y[2]), fabsf(y[3]))));
+            }
           }
         } else if constexpr (EPI == VITSSL_EPI_DGELU) {
           // du = acc * g'  (g' already carries the dropout mask and its scale)
@@ -419,6 +428,11 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
             v[h][2] *= bf_lo(gpv[1]);
             v[h][3] *= bf_hi(gpv[1]);
             out_a[jp][h] = u32x2{pack_bf2(v[h][0], v[h][1]), pack_bf2(v[h][2], v[h][3])};
+            if constexpr (Q8) {
+              out_q[jp][h] = pack_fp8x4(v[h][0] * qs, v[h][1] * qs, v[h][2] * qs, v[h][3] * qs);
+              if (okm && okn[jp][h])
+                qmax = fmaxf(qmax, fmaxf(fmaxf(fabsf(v[h][0]), fabsf(v[h][1])), fmaxf(fabsf(v[h][2]), fabsf(v[h][3]))));
+            }
           }
         } else if constexpr (EPI == EPI_F32_SPLITK) {
 #pragma unroll
@@ -467,7 +481,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
         store_bf16_row(rsOut0, i, out_a, IC<(EPI == VITSSL_EPI_GELU && NT_STORE_AUX == 0) ? NT_GPRIME_AUX : BF16_AUX>{});
       }
       if constexpr (EPI == VITSSL_EPI_GELU) store_bf16_row(rsOut1, i, out_b, IC<BF16_AUX>{});
-      if constexpr (Q8 && EPI == VITSSL_EPI_GELU) {
+      if constexpr (Q8EPI) {
         if (q8) {
           if ((p.N & 15) == 0) {
             // The row's 64 bytes: dword t*4 + g lives in lane row g as out_q of tile t.  A 4x4 transpose over the
@@ -504,6 +518,13 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
         const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4) + r;
         if ((lane & 15) == 0 && n < p.N) atomicAdd(p.colsum + n, s);
       }
+    }
+  }
+  if constexpr (Q8EPI) {
+    if (p.qamax) {          // one atomic per wave and tile at most; skipped when the slot already holds a larger value
+      qmax = wave_max(qmax);
+      unsigned* slot = (unsigned*)p.qamax;
+      if (lane == 0 && __float_as_uint(qmax) > __builtin_nontemporal_load(slot)) atomicMax(slot, __float_as_uint(qmax));
     }
   }
 
@@ -1008,8 +1029,8 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_nt_pp_kernel(NtParams p)
     }
     stamp(round, 1);
     if constexpr (F8) {
-      if (p.alpha) {
-        const float al = *p.alpha;
+      if (p.alpha || p.alpha2) {
+        const float al = (p.alpha ? *p.alpha : 1.0f) * (p.alpha2 ? *p.alpha2 : 1.0f);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -1113,7 +1134,8 @@ int launch_cfg(NtParams p, hipStream_t s) {
   if (p.esz == 1) {
     // fp8 operands exist for the ping-pong loop and the epilogues of the transformer-block forward only
     if constexpr (CFG::WAVES == 8 && CFG::BK == 64 &&
-                  (EPI == VITSSL_EPI_BF16 || EPI == VITSSL_EPI_F32 || EPI == VITSSL_EPI_GELU || EPI == VITSSL_EPI_RESID)) {
+                  (EPI == VITSSL_EPI_BF16 || EPI == VITSSL_EPI_F32 || EPI == VITSSL_EPI_GELU || EPI == VITSSL_EPI_RESID ||
+                   EPI == VITSSL_EPI_DGELU)) {
       return launch_pp<EPI, CFG, true>(p, s);
     } else {
       vitssl_set_error("gemm_fp8_nt: epilogue %d / tile configuration not built for fp8 operands", EPI);
@@ -1251,7 +1273,10 @@ static int gemm_nt_entry(const vitssl_gemm_t* g, int esz, const vitssl_fp8_gemm_
   p.stagger = 0;
   p.esz = esz;
   p.alpha = q ? q->alpha : nullptr;
+  p.alpha2 = q ? q->alpha2 : nullptr;
   p.out2 = q ? q->out_fp8 : nullptr;
+  p.qscale = q ? q->out_scale : nullptr;
+  p.qamax = q ? q->out_amax : nullptr;
 #ifdef VITSSL_NT_STAMPS
   p.stamps = g_nt_stamps;
 #endif
@@ -1283,8 +1308,9 @@ extern "C" int vitssl_gemm_bf16_nt(const vitssl_gemm_t* g, void* stream) { retur
 
 extern "C" int vitssl_gemm_fp8_nt(const vitssl_gemm_t* g, const vitssl_fp8_gemm_t* q, void* stream) {
   VS_CHECK_ARG(g && (g->epilogue == VITSSL_EPI_BF16 || g->epilogue == VITSSL_EPI_F32 || g->epilogue == VITSSL_EPI_GELU ||
-                     g->epilogue == VITSSL_EPI_RESID),
-               "gemm_fp8_nt: fp8 operands are built for the BF16 / F32 / GELU / RESID epilogues");
-  VS_CHECK_ARG(!g->colsum, "gemm_fp8_nt: column sums are a backward-pass feature (bf16 operands)");
+                     g->epilogue == VITSSL_EPI_RESID || g->epilogue == VITSSL_EPI_DGELU),
+               "gemm_fp8_nt: fp8 operands are built for the BF16 / F32 / GELU / RESID / DGELU epilogues");
+  VS_CHECK_ARG(!(q && q->out_fp8) || g->epilogue == VITSSL_EPI_GELU || g->epilogue == VITSSL_EPI_DGELU,
+               "gemm_fp8_nt: out_fp8 belongs to EPI_GELU / EPI_DGELU");
   return gemm_nt_entry(g, 1, q, stream);
 }

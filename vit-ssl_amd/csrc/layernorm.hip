@@ -135,13 +135,16 @@ constexpr int ln_bwd_blocks(int V, bool has_ln, bool has_cs) {
 }
 
 // HAS_LN = false turns the kernel into the plain "mask + cast + column-sum" of g_res.
-template <int V, bool HAS_LN, bool HAS_CS>
+// Q8: also write the e4m3 image gm8 = e4m3(gm * *qscale) and record max |gm| in *qamax (fp8 dgrad operand).
+template <int V, bool HAS_LN, bool HAS_CS, bool Q8 = false>
 __global__ __launch_bounds__(LN_THREADS, ln_bwd_blocks(V, HAS_LN, HAS_CS)) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* g_res,
                                                             float* g_out, bf16_t* __restrict__ gm, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, float* __restrict__ gm_colsum,
-                                                            DropKey dk, int drop_on, long long rows, int cols) {
+                                                            DropKey dk, int drop_on, long long rows, int cols,
+                                                            unsigned char* __restrict__ gm8 = nullptr,
+                                                            const float* __restrict__ qscale = nullptr, float* qamax = nullptr) {
   __shared__ __attribute__((aligned(16))) float red[4][V * 256];   // [wave][col]
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -156,6 +159,8 @@ __global__ __launch_bounds__(LN_THREADS, ln_bwd_blocks(V, HAS_LN, HAS_CS)) void 
     if (HAS_LN && c4 < c4n) g[v] = *(const f32x4*)(gamma + 4 * c4);
   }
   const float inv = 1.0f / (float)cols;
+  const float qs = (Q8 && qscale) ? *qscale : 1.0f;
+  float qmax = 0.f;
   // raw operands of one row (HAS_LN): x, residual gradient, packed dy, statistics
   f32x4 nx[V], ngr[V];
   u32x2 ndy[V];
@@ -270,9 +275,20 @@ __global__ __launch_bounds__(LN_THREADS, ln_bwd_blocks(V, HAS_LN, HAS_CS)) void 
           }
           u32x2 w = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
           *(u32x2*)(gm + row * cols + 4 * c4) = w;
+          if constexpr (Q8) {
+            *(unsigned*)(gm8 + row * cols + 4 * c4) = pack_fp8x4(o[0] * qs, o[1] * qs, o[2] * qs, o[3] * qs);
+            qmax = fmaxf(qmax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+          }
           if (HAS_CS) acc_cs[v] += o;
         }
       }
+    }
+  }
+  if constexpr (Q8) {
+    if (qamax) {
+      qmax = wave_max(qmax);
+      unsigned* slot = (unsigned*)qamax;
+      if (lane == 0 && __float_as_uint(qmax) > __builtin_nontemporal_load(slot)) atomicMax(slot, __float_as_uint(qmax));
     }
   }
   // cross-wave column reduction, one atomic per column per block (LDS buffer reused)
@@ -310,21 +326,24 @@ inline int ln_grid(long long rows, bool fwd = false) {
   return (int)g;
 }
 
-template <bool HAS_LN>
+template <bool HAS_LN, bool Q8 = false>
 int launch_ln_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                   const float* g_res, float* g_out, void* gm, float* dgamma, float* dbeta, float* gm_colsum,
-                  vitssl_dropout_t drop, int64_t rows, int cols, hipStream_t s) {
+                  vitssl_dropout_t drop, int64_t rows, int cols, hipStream_t s, void* gm8 = nullptr,
+                  const float* qscale = nullptr, float* qamax = nullptr) {
   DropKey dk = make_drop_key(drop);
   const int on = dk.thr != 0;
   const int grid = ln_grid(rows);
 #define VS_LNB(V)                                                                                                        \
   do {                                                                                                                   \
     if (gm_colsum)                                                                                                       \
-      hipLaunchKernelGGL((ln_bwd_kernel<V, HAS_LN, true>), dim3(grid), dim3(LN_THREADS), 0, s, (const bf16_t*)dy, x, mean, \
-                         rstd, gamma, g_res, g_out, (bf16_t*)gm, dgamma, dbeta, gm_colsum, dk, on, (long long)rows, cols); \
+      hipLaunchKernelGGL((ln_bwd_kernel<V, HAS_LN, true, Q8>), dim3(grid), dim3(LN_THREADS), 0, s, (const bf16_t*)dy, x, mean, \
+                         rstd, gamma, g_res, g_out, (bf16_t*)gm, dgamma, dbeta, gm_colsum, dk, on, (long long)rows, cols,  \
+                         (unsigned char*)gm8, qscale, qamax);                                                            \
     else                                                                                                                 \
-      hipLaunchKernelGGL((ln_bwd_kernel<V, HAS_LN, false>), dim3(grid), dim3(LN_THREADS), 0, s, (const bf16_t*)dy, x, mean, \
-                         rstd, gamma, g_res, g_out, (bf16_t*)gm, dgamma, dbeta, gm_colsum, dk, on, (long long)rows, cols); \
+      hipLaunchKernelGGL((ln_bwd_kernel<V, HAS_LN, false, Q8>), dim3(grid), dim3(LN_THREADS), 0, s, (const bf16_t*)dy, x, mean, \
+                         rstd, gamma, g_res, g_out, (bf16_t*)gm, dgamma, dbeta, gm_colsum, dk, on, (long long)rows, cols,  \
+                         (unsigned char*)gm8, qscale, qamax);                                                            \
   } while (0)
   if (cols <= 256) VS_LNB(1);
   else if (cols <= 512) VS_LNB(2);
@@ -385,6 +404,24 @@ extern "C" int vitssl_layernorm_bwd(const void* dy_bf16, const float* x, const f
   VS_CHECK_ARG(!gm_colsum || gm_bf16, "layernorm_bwd: gm_colsum without gm_bf16");
   return launch_ln_bwd<true>(dy_bf16, x, mean, rstd, gamma, g_res, g_out, gm_bf16, dgamma, dbeta, gm_colsum, drop, rows,
                              cols, (hipStream_t)stream);
+}
+
+extern "C" int vitssl_layernorm_bwd_fp8(const void* dy_bf16, const float* x, const float* mean, const float* rstd,
+                                        const float* gamma, const float* g_res, float* g_out, void* gm_bf16, void* gm_fp8,
+                                        const float* qscale, float* qamax, float* dgamma, float* dbeta, float* gm_colsum,
+                                        vitssl_dropout_t drop, int64_t rows, int cols, void* stream) {
+  VS_CHECK_ARG(dy_bf16 && x && mean && rstd && gamma && g_out && dgamma && dbeta && gm_bf16 && gm_fp8, "layernorm_bwd_fp8: null pointer");
+  VS_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 2048, "layernorm_bwd_fp8: cols=%d must be a multiple of 4 and <= 2048", cols);
+  return launch_ln_bwd<true, true>(dy_bf16, x, mean, rstd, gamma, g_res, g_out, gm_bf16, dgamma, dbeta, gm_colsum, drop, rows,
+                                   cols, (hipStream_t)stream, gm_fp8, qscale, qamax);
+}
+
+extern "C" int vitssl_grad_mask_cast_fp8(const float* g, void* gm_bf16, void* gm_fp8, const float* qscale, float* qamax,
+                                         float* gm_colsum, vitssl_dropout_t drop, int64_t rows, int cols, void* stream) {
+  VS_CHECK_ARG(g && gm_bf16 && gm_fp8, "grad_mask_cast_fp8: null pointer");
+  VS_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 2048, "grad_mask_cast_fp8: cols=%d must be a multiple of 4 and <= 2048", cols);
+  return launch_ln_bwd<false, true>(nullptr, nullptr, nullptr, nullptr, nullptr, g, nullptr, gm_bf16, nullptr, nullptr,
+                                    gm_colsum, drop, rows, cols, (hipStream_t)stream, gm_fp8, qscale, qamax);
 }
 
 extern "C" int vitssl_grad_mask_cast(const float* g, void* gm_bf16, float* gm_colsum, vitssl_dropout_t drop,

@@ -30,7 +30,8 @@ class Gemm(C.Structure):
 
 
 class Fp8Gemm(C.Structure):
-    _fields_ = [("alpha", C.c_void_p), ("out_fp8", C.c_void_p)]
+    _fields_ = [("alpha", C.c_void_p), ("alpha2", C.c_void_p), ("out_fp8", C.c_void_p), ("out_scale", C.c_void_p),
+                ("out_amax", C.c_void_p)]
 
 
 EPI_BF16, EPI_F32, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_EMBED = range(6)
@@ -47,6 +48,9 @@ PROTOTYPES = {
     "vitssl_gemm_bf16_tn": [_vp, _vp, _vp, _i64, _i, _i, _vp, _i64, _vp],
     "vitssl_gemm_fp8_nt": [C.POINTER(Gemm), C.POINTER(Fp8Gemm), _vp],
     "vitssl_quantize_fp8": [_vp, _vp, _i64, _vp],
+    "vitssl_quantize_fp8_scaled": [_vp, _vp, _i64, _vp, _vp, _vp],
+    "vitssl_layernorm_bwd_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, Dropout, _i64, _i, _vp],
+    "vitssl_grad_mask_cast_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, Dropout, _i64, _i, _vp],
     "vitssl_attn_fwd_fp8": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "vitssl_layernorm_fwd_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _vp],
     "vitssl_fp8_quantize_weights": [_vp, _vp, _i, _i, _vp, _vp, _vp],

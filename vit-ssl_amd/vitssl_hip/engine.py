@@ -172,8 +172,9 @@ class FlatStore:
         self._cast_jobs.append((key, src, transposed_too, plain))
 
     def register_fp8_weight(self, key: str, src: Callable[[], torch.Tensor]):
-        """Declare a 2-D GEMM weight [N,K] whose forward operand is an e4m3 image with a per-tensor
-        power-of-two scale: `w8(key)` returns (image, dequantisation factor as a 1-element device tensor)."""
+        """Declare a 2-D GEMM weight [N,K] whose GEMM operands are e4m3 images with a per-tensor power-of-two
+        scale: `w8(key)` returns (image [N,K], dequantisation factor as a 1-element device tensor), `w8t(key)`
+        the transposed image [K,N] (operand of the input-gradient GEMM) with the same factor."""
         self._fp8_jobs.append((key, src))
 
     def refresh_weights(self):
@@ -203,11 +204,13 @@ class FlatStore:
             jobs8 = []
             for k8, src in self._fp8_jobs:
                 w = src()
-                dst = self._fp8.get(k8)
-                if dst is None or dst.shape != w.shape:
-                    dst = torch.empty(w.shape, dtype=FP8, device=self.device)
-                    self._fp8[k8] = dst
-                jobs8.append((w.contiguous(), dst))
+                R, Cn = w.shape
+                dst, dst_t = self._fp8.get(k8), self._fp8.get(k8 + ".T")
+                if dst is None or dst.shape != (R, Cn):
+                    dst = torch.empty(R, Cn, dtype=FP8, device=self.device)
+                    dst_t = torch.empty(Cn, R, dtype=FP8, device=self.device)
+                    self._fp8[k8], self._fp8[k8 + ".T"] = dst, dst_t
+                jobs8.append((w.contiguous(), dst, dst_t))
             if self._fp8_plan is None:
                 self._fp8_plan = ops.Fp8WeightPlan()
             self._fp8_plan.run(jobs8)
@@ -219,6 +222,10 @@ class FlatStore:
     def w8(self, key: str) -> Tuple[torch.Tensor, torch.Tensor]:
         j = next(i for i, (k8, _) in enumerate(self._fp8_jobs) if k8 == key)
         return self._fp8[key], self._fp8_plan.alpha[j:j + 1]
+
+    def w8t(self, key: str) -> Tuple[torch.Tensor, torch.Tensor]:
+        j = next(i for i, (k8, _) in enumerate(self._fp8_jobs) if k8 == key)
+        return self._fp8[key + ".T"], self._fp8_plan.alpha[j:j + 1]
 
 
 class GradReducer:
@@ -340,10 +347,16 @@ class EncoderStack:
                 "w2": lambda b=b: store.view(b + "feed_forward.linear_out.weight", (D, F)),
             }
             for leaf, src in srcs.items():
-                # fp8 operands: the forward reads the e4m3 image, the dgrad GEMM still the bf16 transpose
-                store.register_weight(b + leaf, src, plain=not self.fp8)
-                if self.fp8:
+                if self.fp8:      # e4m3 images [N,K] (forward) and [K,N] (input gradients); no bf16 copies
                     store.register_fp8_weight(b + leaf, src)
+                else:
+                    store.register_weight(b + leaf, src)
+        # fp8: per block, scales of the four gradient tensors that feed an input-gradient GEMM
+        # (0: d(FFN out) -> FC2, 1: d(FFN hidden) -> FC1, 2: d(attention out) -> out-projection, 3: dQKV -> QKV).
+        # Delayed scaling: a step quantises with the power-of-two scale derived from the PREVIOUS step's max |value|
+        # (one bit of headroom); the very first backward derives each scale from the tensor itself (one extra pass).
+        self._gs = None            # dict of device tensors, allocated on first use
+        self._gs_valid = False
 
     # names ----------------------------------------------------------------
     def _n(self, i, leaf):
@@ -426,6 +439,8 @@ class EncoderStack:
         """g: fp32 [M, D] gradient wrt the stack output (overwritten in place; returned
         holding the gradient wrt the stack input).  Parameter gradients are ACCUMULATED
         into the store's flat gradient buffer."""
+        if self.fp8:
+            return self._backward_fp8(g, slot, reducer)
         st, D, H, F, dh = self.store, self.D, self.H, self.F, self.dh
         rec = self._saved[slot]
         B, T, seed, training = rec["B"], rec["T"], rec["seed"], rec["training"]
@@ -471,4 +486,111 @@ class EncoderStack:
                 # which belongs to the next (lower) range
                 lo, hi = self.block_span(i)
                 reducer.ready(lo, hi)
+        return g
+
+    # fp8 input-gradient GEMMs ----------------------------------------------------
+    @staticmethod
+    def _scale_from_amax(amax: torch.Tensor, margin: int) -> torch.Tensor:
+        """2^(floor(log2(448 / amax)) - margin) on the binary representation (the rule of csrc/fp8.hip)."""
+        mant, e = torch.frexp(amax)                     # amax = mant * 2^e, mant in [0.5, 1)
+        k = (9 - e - (mant > 0.875).to(e.dtype) - margin).clamp(-120, 120)
+        # an exact power of two from its exponent field (torch.ldexp multiplies by pow(2, k), which is not exact on the GPU)
+        return torch.bitwise_left_shift(k.to(torch.int32) + 127, 23).view(torch.float32)
+
+    def _grad_scale_state(self, dev):
+        if self._gs is None or self._gs["scale"].device != dev:
+            mk = lambda v: torch.full((self.L, 4), v, dtype=F32, device=dev)  # noqa: E731
+            self._gs = {"scale": mk(1.0), "inv": mk(1.0), "amax": mk(0.0), "used": mk(1.0)}
+            self._gs_valid = False
+        return self._gs
+
+    def _rescale(self, sel, margin: int):
+        """scale / inv of the selected entries from their recorded max |value| (left alone where that is 0 or not finite)."""
+        gs = self._gs
+        a = gs["amax"][sel]
+        ok = (a > 0) & torch.isfinite(a)
+        new = torch.where(ok, self._scale_from_amax(torch.where(ok, a, torch.ones_like(a)), margin), gs["scale"][sel])
+        gs["scale"][sel] = new
+        gs["inv"][sel] = 1.0 / new
+
+    def fp8_grad_scales(self) -> torch.Tensor:
+        """[L, 4] scales the last backward quantised its gradient operands with (tests hand them to the oracle)."""
+        return self._gs["used"].clone()
+
+    def recalibrate_fp8(self):
+        """Derive the gradient scales from the tensors themselves in the next backward (as the first one does)."""
+        self._gs_valid = False
+
+    def _backward_fp8(self, g: torch.Tensor, slot: str, reducer: Optional[GradReducer]) -> torch.Tensor:
+        """The schedule of backward() with the four input-gradient GEMMs of every block on e4m3 operands: the
+        transposed weight images of the store, and gradient images written by the producers of the gradients
+        (LayerNorm backward, the dGELU epilogue, a quantising pass over dQKV) next to the bf16 images the
+        weight-gradient GEMMs keep reading."""
+        st, D, H, F, dh = self.store, self.D, self.H, self.F, self.dh
+        rec = self._saved[slot]
+        B, T, seed, training = rec["B"], rec["T"], rec["seed"], rec["training"]
+        M = B * T
+        dev = g.device
+        w = self.ws.get
+        gm, gm8 = w("bwd.gm", (M, D), BF16, dev), w("bwd.gm8", (M, D), FP8, dev)
+        du, du8 = w("bwd.du", (M, F), BF16, dev), w("bwd.du8", (M, F), FP8, dev)
+        dqkv, dq8 = w("bwd.dqkv", (M, 3 * D), BF16, dev), w("bwd.dq8", (M, 3 * D), FP8, dev)
+        dh_ = w("bwd.dh", (M, D), BF16, dev)
+        delta = w("bwd.delta", (B, H, T), F32, dev)
+        gv = st.gview
+        gs = self._grad_scale_state(dev)
+        sc = lambda i, t: gs["scale"][i, t:t + 1]   # noqa: E731
+        inv = lambda i, t: gs["inv"][i, t:t + 1]    # noqa: E731
+        am = lambda i, t: gs["amax"][i, t:t + 1]    # noqa: E731
+        jit = not self._gs_valid
+
+        def settle(i, t, x, x8):
+            """first backward only: the producer has just recorded max|x|; take the scale from it and quantise again"""
+            if jit:
+                self._rescale((slice(i, i + 1), slice(t, t + 1)), margin=0)
+                ops.quantize_fp8(x, x8, scale=sc(i, t))
+
+        last = self.L - 1
+        ops.grad_mask_cast_fp8(g, gm, gm8, sc(last, 0), am(last, 0), gv(self._n(last, "feed_forward.linear_out.bias")),
+                               self._drop(last, 2, seed, training))
+        settle(last, 0, gm, gm8)
+        for i in range(last, -1, -1):
+            s = rec["blocks"][i]
+            a_ = self.bp[i] + "self_attention."
+            (w2t, a2), (w1t, a1), (wot, ao), (wqt, aq) = (st.w8t(self._n(i, k)) for k in ("w2", "w1", "wo", "wqkv"))
+            # MLP
+            ops.gemm_fp8_nt(gm8, w2t, du, L.EPI_DGELU, alpha=a2, alpha2=inv(i, 0), aux=s["u"],
+                            colsum=gv(self._n(i, "feed_forward.linear_in.bias")), out_fp8=du8, out_scale=sc(i, 1), out_amax=am(i, 1))
+            settle(i, 1, du, du8)
+            ops.gemm_tn(gm, s["a"], gv(self._n(i, "feed_forward.linear_out.weight"), (D, F)))
+            ops.gemm_fp8_nt(du8, w1t, dh_, L.EPI_BF16, alpha=a1, alpha2=inv(i, 1))
+            ops.gemm_tn(du, s["h2"], gv(self._n(i, "feed_forward.linear_in.weight"), (F, D)))
+            ops.layernorm_bwd_fp8(dh_, s["xmid"], s["mean2"], s["rstd2"], st.view(self._n(i, "layer_norm2.weight")), g, g, gm, gm8,
+                                  sc(i, 2), am(i, 2), gv(self._n(i, "layer_norm2.weight")), gv(self._n(i, "layer_norm2.bias")), None,
+                                  self._drop(i, 0, seed, training))
+            settle(i, 2, gm, gm8)
+            # attention
+            ops.gemm_fp8_nt(gm8, wot, dh_, L.EPI_BF16, alpha=ao, alpha2=inv(i, 2))
+            ops.gemm_tn(gm, s["att"], gv(a_ + "final_linear.weight", (D, D)))
+            ops.attn_bwd(s["qkv"], s["att"], dh_, s["lse"], dqkv, delta, B, T, H, dh)
+            ops.quantize_fp8(dqkv, dq8, scale=sc(i, 3), amax=am(i, 3))
+            settle(i, 3, dqkv, dq8)
+            ops.gemm_fp8_nt(dq8, wqt, dh_, L.EPI_BF16, alpha=aq, alpha2=inv(i, 3))
+            ops.gemm_tn(dqkv, s["h1"], st.span_view(a_ + "w_query.weight", a_ + "w_value.weight", (3 * D, D), grad=True))
+            if i > 0:
+                ops.layernorm_bwd_fp8(dh_, s["xin"], s["mean1"], s["rstd1"], st.view(self._n(i, "layer_norm1.weight")), g, g, gm, gm8,
+                                      sc(i - 1, 0), am(i - 1, 0), gv(self._n(i, "layer_norm1.weight")), gv(self._n(i, "layer_norm1.bias")),
+                                      gv(self._n(i - 1, "feed_forward.linear_out.bias")), self._drop(i - 1, 2, seed, training))
+                settle(i - 1, 0, gm, gm8)
+            else:
+                ops.layernorm_bwd(dh_, s["xin"], s["mean1"], s["rstd1"], st.view(self._n(i, "layer_norm1.weight")), g, g, None,
+                                  gv(self._n(i, "layer_norm1.weight")), gv(self._n(i, "layer_norm1.bias")), None, ops.NO_DROP)
+            if reducer is not None:
+                lo, hi = self.block_span(i)
+                reducer.ready(lo, hi)
+        # scales of the NEXT backward: this step's max |value| with one bit of headroom
+        gs["used"].copy_(gs["scale"])
+        self._rescale((slice(None), slice(None)), margin=1)
+        gs["amax"].zero_()
+        self._gs_valid = True
         return g

@@ -93,9 +93,37 @@ def layernorm_fwd_fp8(x, gamma, beta, y, y8, mean, rstd, eps=1e-5):
     _prof_end(ev, "ln_fwd", 0.0, rows * (7 * cols + 8))
 
 
-def quantize_fp8(x, y8):
-    """y8 = e4m3(clamp(x, +-448)) of a bf16 tensor (unit scale)."""
-    call("vitssl_quantize_fp8", _chk(x, BF16, "x"), _chk(y8, FP8, "y8", x.shape), x.numel(), _stream())
+def _scalar(t, name):
+    if t is None:
+        return C.c_void_p(0)
+    if t.numel() != 1:
+        raise L.VitsslError(f"{name}: expected a 1-element fp32 device tensor")
+    return _chk(t, F32, name)
+
+
+def quantize_fp8(x, y8, scale=None, amax=None):
+    """y8 = e4m3(clamp(x * scale, +-448)) of a bf16 tensor; `scale` / `amax` are optional 1-element device tensors
+    (amax receives max(amax, max|x|))."""
+    call("vitssl_quantize_fp8_scaled", _chk(x, BF16, "x"), _chk(y8, FP8, "y8", x.shape), x.numel(), _scalar(scale, "scale"),
+         _scalar(amax, "amax"), _stream())
+
+
+def layernorm_bwd_fp8(dy, x, mean, rstd, gamma, g_res, g_out, gm, gm8, scale, amax, dgamma, dbeta, gm_colsum=None, drop=NO_DROP):
+    """layernorm_bwd that also writes gm8 = e4m3(gm * scale) and records max|gm| in amax."""
+    rows, cols = x.shape
+    ev = _prof_begin()
+    call("vitssl_layernorm_bwd_fp8", _chk(dy, BF16, "dy", (rows, cols)), _chk(x, F32, "x"), _chk(mean, F32, "mean", (rows,)),
+         _chk(rstd, F32, "rstd", (rows,)), _chk(gamma, F32, "gamma", (cols,)), _opt(g_res, F32, "g_res", (rows, cols)),
+         _chk(g_out, F32, "g_out", (rows, cols)), _chk(gm, BF16, "gm", (rows, cols)), _chk(gm8, FP8, "gm8", (rows, cols)),
+         _scalar(scale, "scale"), _scalar(amax, "amax"), _chk(dgamma, F32, "dgamma", (cols,)), _chk(dbeta, F32, "dbeta", (cols,)),
+         _opt(gm_colsum, F32, "gm_colsum", (cols,)), drop, rows, cols, _stream())
+    _prof_end(ev, "ln_bwd", 0.0, rows * (cols * (2 + 4 + (4 if g_res is not None else 0) + 4 + 3) + 8))
+
+
+def grad_mask_cast_fp8(g, gm, gm8, scale, amax, gm_colsum=None, drop=NO_DROP):
+    rows, cols = g.shape
+    call("vitssl_grad_mask_cast_fp8", _chk(g, F32, "g"), _chk(gm, BF16, "gm", (rows, cols)), _chk(gm8, FP8, "gm8", (rows, cols)),
+         _scalar(scale, "scale"), _scalar(amax, "amax"), _opt(gm_colsum, F32, "gm_colsum", (cols,)), drop, rows, cols, _stream())
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, g_res, g_out, gm, dgamma, dbeta, gm_colsum=None, drop=NO_DROP):
@@ -157,15 +185,17 @@ def gemm_nt(A, B, out0, epilogue, bias=None, aux=None, out1=None, colsum=None, d
     _prof_end(ev, f"gemm_nt[epi{epilogue}] {M}x{N}x{K}", 2.0 * M * N * K)
 
 
-def gemm_fp8_nt(A8, B8, out0, epilogue, alpha=None, bias=None, aux=None, out1=None, out_fp8=None, drop=NO_DROP):
-    """out = alpha * (A8[M,K] @ B8[N,K]^T) with the fused epilogue; A8 / B8 are e4m3 operands, `alpha` a device
-    scalar (fp32 tensor with one element: the product of the dequantisation scales), `out_fp8` the optional e4m3
-    image of out1 (EPI_GELU).  Forward GEMMs only (include/vitssl_hip.h)."""
+def gemm_fp8_nt(A8, B8, out0, epilogue, alpha=None, bias=None, aux=None, out1=None, out_fp8=None, drop=NO_DROP,
+                alpha2=None, colsum=None, out_scale=None, out_amax=None):
+    """out = alpha * alpha2 * (A8[M,K] @ B8[N,K]^T) with the fused epilogue; A8 / B8 are e4m3 operands, `alpha` /
+    `alpha2` 1-element device tensors (dequantisation factors of the two operands).  `out_fp8`: optional e4m3 image of
+    out1 (EPI_GELU) or of out0 (EPI_DGELU), written as e4m3(value * out_scale) with max|value| recorded in out_amax.
+    Forward and input-gradient GEMMs (include/vitssl_hip.h)."""
     M, K = A8.shape
     N, K2 = B8.shape
     if K != K2:
         raise L.VitsslError(f"gemm_fp8_nt: K mismatch {K} vs {K2}")
-    if epilogue not in (L.EPI_BF16, L.EPI_F32, L.EPI_GELU, L.EPI_RESID):
+    if epilogue not in (L.EPI_BF16, L.EPI_F32, L.EPI_GELU, L.EPI_RESID, L.EPI_DGELU):
         raise L.VitsslError(f"gemm_fp8_nt: epilogue {epilogue} has no fp8-operand form")
     g = Gemm()
     g.A = _chk(A8, FP8, "A8")
@@ -176,17 +206,19 @@ def gemm_fp8_nt(A8, B8, out0, epilogue, alpha=None, bias=None, aux=None, out1=No
     g.out0 = _chk(out0, _OUT0_DTYPE[epilogue], "out0", (M, N))
     if epilogue == L.EPI_RESID:
         g.aux = _chk(aux, F32, "aux(residual)", (M, N))
+    elif epilogue == L.EPI_DGELU:
+        g.aux = _chk(aux, BF16, "aux(g')", (M, N))
     g.out1 = _opt(out1, BF16, "out1", (M, N))
+    g.colsum = _opt(colsum, F32, "colsum", (N,))
     g.drop = drop
     q = Fp8Gemm()
-    q.alpha = C.c_void_p(0)
-    if alpha is not None:
-        if alpha.numel() != 1:
-            raise L.VitsslError("gemm_fp8_nt: alpha must hold one fp32 element")
-        q.alpha = _chk(alpha, F32, "alpha")
+    q.alpha = _scalar(alpha, "alpha")
+    q.alpha2 = _scalar(alpha2, "alpha2")
     q.out_fp8 = _opt(out_fp8, FP8, "out_fp8", (M, N))
-    if out_fp8 is not None and epilogue != L.EPI_GELU:
-        raise L.VitsslError("gemm_fp8_nt: out_fp8 belongs to EPI_GELU")
+    q.out_scale = _scalar(out_scale, "out_scale")
+    q.out_amax = _scalar(out_amax, "out_amax")
+    if out_fp8 is not None and epilogue not in (L.EPI_GELU, L.EPI_DGELU):
+        raise L.VitsslError("gemm_fp8_nt: out_fp8 belongs to EPI_GELU / EPI_DGELU")
     ev = _prof_begin()
     call("vitssl_gemm_fp8_nt", C.byref(g), C.byref(q), _stream())
     _prof_end(ev, f"gemm_fp8_nt[epi{epilogue}] {M}x{N}x{K}", 2.0 * M * N * K)
@@ -360,7 +392,6 @@ class CastPlan:
 class Fp8WeightPlan:
     """Device-resident job table for `vitssl_fp8_quantize_weights` (per-tensor power-of-two scales computed on the
     device, no host synchronisation): `alpha` holds one dequantisation factor per job."""
-    CHUNK = 4096
 
     def __init__(self):
         self.key = None
@@ -369,18 +400,20 @@ class Fp8WeightPlan:
         self.keep = None
 
     def run(self, jobs):
-        """jobs: list of (src f32 [..], dst e4m3 same shape)."""
+        """jobs: list of (src f32 [R,C], dst e4m3 [R,C] | None, dst_t e4m3 [C,R] | None)."""
         import numpy as np
-        key = tuple((s.data_ptr(), d.data_ptr(), s.numel()) for s, d in jobs)
+        key = tuple((s.data_ptr(), 0 if d is None else d.data_ptr(), 0 if t is None else t.data_ptr(), s.shape[0], s.shape[1])
+                    for s, d, t in jobs)
         if key != self.key:
-            for s, d in jobs:
-                _chk(s, F32, "src"); _chk(d, FP8, "dst", s.shape)
+            for s, d, t in jobs:
+                R, Cn = s.shape
+                _chk(s, F32, "src"); _opt(d, FP8, "dst", (R, Cn)); _opt(t, FP8, "dst_t", (Cn, R))
             dev = jobs[0][0].device
-            rec = np.zeros(len(jobs), dtype=np.dtype([("src", "<u8"), ("dst", "<u8"), ("n", "<i8")]))
+            rec = np.zeros(len(jobs), dtype=np.dtype([("src", "<u8"), ("dst", "<u8"), ("dst_t", "<u8"), ("R", "<i4"), ("C", "<i4")]))
             starts = np.zeros(len(jobs) + 1, dtype=np.int32)
             for i, k in enumerate(key):
                 rec[i] = k
-                starts[i + 1] = starts[i] + (k[2] + self.CHUNK - 1) // self.CHUNK
+                starts[i + 1] = starts[i] + ((k[3] + 63) // 64) * ((k[4] + 63) // 64)
             self.jobs_dev = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
             self.starts_dev = torch.from_numpy(starts).to(dev)
             self.amax = torch.zeros(len(jobs), dtype=F32, device=dev)
