@@ -137,6 +137,9 @@ int vitssl_gemm_fp8_nt(const vitssl_gemm_t* g, const vitssl_fp8_gemm_t* q, void*
 /* vitssl_attn_fwd that also writes the e4m3 image of `out` (made from the fp32 values before the bf16 store) */
 int vitssl_attn_fwd_fp8(const void* qkv, void* out, void* out_fp8, float* lse, float* probs, int B, int N, int H, int dh,
                         void* stream);
+/* vitssl_attn_bwd (one-launch form) that also writes dqkv_fp8 = e4m3(dqkv * *qscale) and records max|dqkv| in *qamax */
+int vitssl_attn_bwd_fp8(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, void* dqkv_fp8,
+                        const float* qscale, float* qamax, int B, int N, int H, int dh, void* stream);
 /* y_fp8[n] = e4m3(clamp(x, -448, 448)), round to nearest even (activations are quantised at unit scale) */
 int vitssl_quantize_fp8(const void* x_bf16, void* y_fp8, int64_t n, void* stream);
 /* y_fp8[n] = e4m3(x * *qscale) (qscale NULL = 1); *qamax = max(*qamax, max|x|) (NULL = not recorded; caller zeroes) */

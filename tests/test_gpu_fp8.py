@@ -175,6 +175,29 @@ def test_attention_fwd_fp8_image():
     assert float(same) > 0.95    # expected ~0.97: 1 in 2^5 values sits where the two roundings disagree
 
 
+def test_attention_bwd_fp8_image():
+    from vitssl_hip import ops
+    torch.manual_seed(5)
+    B, N, H, dh = 2, 197, 3, 64
+    qkv = torch.randn(B * N, 3 * H * dh).to(torch.bfloat16).to(DEV)
+    out = torch.empty(B * N, H * dh, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B, H, N, device=DEV)
+    ops.attn_fwd(qkv, out, lse, B, N, H, dh)
+    dout = (torch.randn(B * N, H * dh) * 1e-3).to(torch.bfloat16).to(DEV)
+    d0, d1 = (torch.empty(B * N, 3 * H * dh, dtype=torch.bfloat16, device=DEV) for _ in range(2))
+    d8 = torch.empty(B * N, 3 * H * dh, dtype=FP8, device=DEV)
+    delta = torch.empty(B, H, N, device=DEV)
+    ops.attn_bwd(qkv, out, dout, lse, d0, delta, B, N, H, dh)
+    scale, amax = torch.tensor([2.0 ** 13], device=DEV), torch.zeros(1, device=DEV)
+    ops.attn_bwd(qkv, out, dout, lse, d1, delta, B, N, H, dh, dqkv_fp8=d8, scale=scale, amax=amax)
+    assert torch.equal(d0, d1)
+    # the image is made from the fp32 accumulators, the bf16 tensor is a finer rounding of the same values
+    assert abs(float(amax) - float(d1.float().abs().max())) <= 2.0 ** -8 * float(amax)
+    same = (d8.cpu().view(torch.uint8) == _q8_torch(d1.cpu().float() * 2.0 ** 13).view(torch.uint8)).float().mean()
+    assert float(same) > 0.95
+    assert rel_l2(_f32(d8) / 2.0 ** 13, d1) < 4e-2
+
+
 SHAPES = [(300, 128, 128), (1000, 384, 256), (517, 260, 1024), (4096, 512, 512)]
 
 

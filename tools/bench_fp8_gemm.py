@@ -44,7 +44,21 @@ def main():
             "gelu+drop": (lambda: ops.gemm_nt(A16, B16, o16, L.EPI_GELU, bias=bias, out1=o16b, drop=drop),
                           lambda: ops.gemm_fp8_nt(A8, B8, o16, L.EPI_GELU, alpha=alpha, bias=bias, out1=o16b, out_fp8=o8, drop=drop)),
         }
+        gp = (torch.rand(M, N, device=DEV)).to(torch.bfloat16)
+        cs = torch.zeros(N, device=DEV)
+        qs, qa, a2 = torch.tensor([4.0], device=DEV), torch.zeros(1, device=DEV), torch.tensor([0.5], device=DEV)
+        cases["dgelu+colsum"] = (lambda: ops.gemm_nt(A16, B16, o16, L.EPI_DGELU, aux=gp, colsum=cs),
+                                 lambda: ops.gemm_fp8_nt(A8, B8, o16, L.EPI_DGELU, alpha=alpha, alpha2=a2, aux=gp, colsum=cs,
+                                                         out_fp8=o8, out_scale=qs, out_amax=qa))
+        cases["dgelu (fp8: no image)"] = (lambda: ops.gemm_nt(A16, B16, o16, L.EPI_DGELU, aux=gp, colsum=cs),
+                                          lambda: ops.gemm_fp8_nt(A8, B8, o16, L.EPI_DGELU, alpha=alpha, alpha2=a2, aux=gp, colsum=cs))
+        cases["dgelu (fp8: image, no amax)"] = (lambda: ops.gemm_nt(A16, B16, o16, L.EPI_DGELU, aux=gp, colsum=cs),
+                                                lambda: ops.gemm_fp8_nt(A8, B8, o16, L.EPI_DGELU, alpha=alpha, alpha2=a2, aux=gp, colsum=cs,
+                                                                        out_fp8=o8, out_scale=qs))
+        only = os.environ.get("CASES")
         for name, fns in cases.items():
+            if only and not any(name.startswith(c) for c in only.split(",")):
+                continue
             for f in fns:
                 f(); f()
             torch.cuda.synchronize()
@@ -63,7 +77,7 @@ def main():
             for li in range(2):
                 ts = sorted(a.elapsed_time(b) / iters * 1e3 for a, b in times[li])
                 med.append(ts[len(ts) // 2])
-            print(f"nt {M}x{N}x{K:5d} {name:11s} | bf16 {med[0]:7.1f} us {fl / med[0] / 1e6:6.0f} TF/s | fp8 {med[1]:7.1f} us "
+            print(f"nt {M}x{N}x{K:5d} {name:28s} | bf16 {med[0]:7.1f} us {fl / med[0] / 1e6:6.0f} TF/s | fp8 {med[1]:7.1f} us "
                   f"{fl / med[1] / 1e6:6.0f} TF/s | x{med[0] / med[1]:.2f}", flush=True)
 
 

@@ -138,6 +138,15 @@ __device__ __forceinline__ void store_row_pair16(bf16_t* row, int p, int g, cons
   const u32x4 v = {lo[0], hi[0], lo[1], hi[1]};
   *(u32x4*)(row + (2 * p + odd) * 16 + 4 * (g - odd)) = v;
 }
+// d[t] of lane row g = dword t*4 + g of a 16-dword row  ->  lane row g gets dwords 4g .. 4g+3 (v_permlane32_swap trades
+// the wave halves, v_permlane16_swap the odd / even lane rows)
+__device__ __forceinline__ u32x4 lane_rows_transpose4(const unsigned (&d)[4]) {
+  auto s02 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
+  auto s13 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
+  auto e = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+  auto f = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+  return u32x4{e[0], e[1], f[0], f[1]};
+}
 __device__ __forceinline__ u32x2 pack4(const f32x4& o) { return u32x2{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])}; }
 
 // ------------------------------------------------------------------ forward
@@ -576,10 +585,14 @@ template <int NS, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ outp,
                                                              const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                              bf16_t* __restrict__ dqkv, int N, int H, int stagger_wgs,
-                                                             int stagger_ticks) {
+                                                             int stagger_ticks, unsigned char* __restrict__ dq8,
+                                                             const float* __restrict__ qscale, float* qamax) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int Np = 32 * NS;
   constexpr int SROW = Np * 2 + 16;
+  // fp8 path: dq8 = e4m3(dqkv * *qscale) written next to the bf16 image, max |dqkv| recorded in *qamax
+  const float qsc = (dq8 && qscale) ? *qscale : 1.0f;
+  float qmax = 0.f;
   startup_stagger(stagger_wgs, stagger_ticks);     // exchange-image row (bytes); +16 makes the 8-byte column reads conflict-free
   char* Qt = smem;
   char* Dt = Qt + Np * ROWB;
@@ -688,6 +701,11 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(const bf16_t* _
     if (q < N) {
       const u32x2 w = {pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3])};
       *(u32x2*)(dqkv + ((long long)b * N + q) * stride + h * DH + dt_w * 16 + 4 * g) = w;
+      if (dq8) {
+        *(unsigned*)(dq8 + ((long long)b * N + q) * stride + h * DH + dt_w * 16 + 4 * g) =
+            pack_fp8x4(acc[0] * qsc, acc[1] * qsc, acc[2] * qsc, acc[3] * qsc);
+        qmax = fmaxf(qmax, fmaxf(fmaxf(fabsf(acc[0]), fabsf(acc[1])), fmaxf(fabsf(acc[2]), fabsf(acc[3]))));
+      }
     }
   };
   auto dq_tile = [&](const char* sx, int qs) {
@@ -768,7 +786,31 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(const bf16_t* _
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) store_row_pair16(dvg, pr, g, pack4(dv[2 * pr][kt]), pack4(dv[2 * pr + 1][kt]));
       }
+      if (dq8) {    // wave-uniform.  The row's 64 bytes: a 4x4 transpose over the four lane rows gives every lane 16 contiguous bytes
+        unsigned qk[4], qv[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const f32x4 a = dk[dt][kt], c = dv[dt][kt];
+          qk[dt] = pack_fp8x4(a[0] * qsc, a[1] * qsc, a[2] * qsc, a[3] * qsc);
+          qv[dt] = pack_fp8x4(c[0] * qsc, c[1] * qsc, c[2] * qsc, c[3] * qsc);
+          if (key < N) {
+            qmax = fmaxf(qmax, fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3]))));
+            qmax = fmaxf(qmax, fmaxf(fmaxf(fabsf(c[0]), fabsf(c[1])), fmaxf(fabsf(c[2]), fabsf(c[3]))));
+          }
+        }
+        const u32x4 rk = lane_rows_transpose4(qk), rv = lane_rows_transpose4(qv);
+        if (key < N) {
+          unsigned char* k8 = dq8 + ((long long)b * N + key) * stride + (long long)H * DH + h * DH + 16 * g;
+          *(u32x4*)k8 = rk;
+          *(u32x4*)(k8 + (long long)H * DH) = rv;
+        }
+      }
     }
+  }
+  if (dq8 && qamax) {
+    qmax = wave_max(qmax);
+    unsigned* slot = (unsigned*)qamax;
+    if (lane == 0 && __float_as_uint(qmax) > __builtin_nontemporal_load(slot)) atomicMax(slot, __float_as_uint(qmax));
   }
 #ifdef VITSSL_ATTN_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -838,15 +880,15 @@ bool attn_bwd_split() {
 
 template <int NS>
 int launch_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, float* delta, bf16_t* dqkv, int B,
-               int N, int H, hipStream_t s) {
-  if (!attn_bwd_split()) {
+               int N, int H, hipStream_t s, unsigned char* dq8 = nullptr, const float* qscale = nullptr, float* qamax = nullptr) {
+  if (!attn_bwd_split() || dq8) {
     static bool done_f = false;
     constexpr int NW = NS <= 2 ? 2 : (NS <= 4 ? 4 : 8);
     const int lds_f = 3 * NS * 32 * ROWB + 2 * 32 * (NS * 64 + 16) + 2 * NS * 32 * 4;
     if (int rc = ensure_lds(attn_bwd_fused_kernel<NS, NW>, lds_f, &done_f, "attn_bwd_fused")) return rc;
     const int per_cu = lds_f > 80 * 1024 ? 1 : 2;
     hipLaunchKernelGGL((attn_bwd_fused_kernel<NS, NW>), dim3(B * H), dim3(64 * NW), lds_f, s, qkv, out, dout, lse, dqkv, N, H,
-                       attn_cu_count() * per_cu, B * H > 2 * attn_cu_count() * per_cu ? attn_stagger_ticks(1) : 0);
+                       attn_cu_count() * per_cu, B * H > 2 * attn_cu_count() * per_cu ? attn_stagger_ticks(1) : 0, dq8, qscale, qamax);
     VS_CHECK_LAUNCH("attn_bwd_fused");
     return VITSSL_OK;
   }
@@ -914,6 +956,17 @@ extern "C" int vitssl_attn_bwd(const void* qkv, const void* out, const void* dou
   if (int rc = check_attn_shape("attn_bwd", B, N, H, dh)) return rc;
   hipStream_t s = (hipStream_t)stream;
 #define VS_CALL(NS) launch_bwd<NS>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, delta_ws, (bf16_t*)dqkv, B, N, H, s)
+  VS_NS_SWITCH((N + 31) / 32, VS_CALL)
+#undef VS_CALL
+}
+
+extern "C" int vitssl_attn_bwd_fp8(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, void* dqkv_fp8,
+                                   const float* qscale, float* qamax, int B, int N, int H, int dh, void* stream) {
+  VS_CHECK_ARG(qkv && out && dout && lse && dqkv && dqkv_fp8, "attn_bwd_fp8: null pointer");
+  if (int rc = check_attn_shape("attn_bwd_fp8", B, N, H, dh)) return rc;
+  hipStream_t s = (hipStream_t)stream;
+#define VS_CALL(NS) launch_bwd<NS>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, nullptr, (bf16_t*)dqkv, B, N, H, s, \
+                                   (unsigned char*)dqkv_fp8, qscale, qamax)
   VS_NS_SWITCH((N + 31) / 32, VS_CALL)
 #undef VS_CALL
 }

@@ -65,22 +65,19 @@ __global__ __launch_bounds__(Q_THREADS) void fp8_weight_amax_kernel(const vitssl
   __shared__ float red[Q_THREADS / 64];
   const int j = find_job(tile_start, njobs, blockIdx.x);
   const vitssl_fp8_weight_job_t job = jobs[j];
-  const int t = blockIdx.x - tile_start[j];
-  const int tx_n = (job.C + 63) >> 6;
-  const int r0 = (t / tx_n) * 64, c0 = (t % tx_n) * 64;
-  const int tx = (threadIdx.x & 15) * 4, ty = threadIdx.x >> 4;     // 16 threads x 4 columns per row, 16 rows per pass
+  // the tensor is contiguous: workgroup t of the job's ceil(R/64) * ceil(C/64) >= R*C / 4096 workgroups scans the
+  // linear chunk [4096 t, 4096 (t+1)) (whole cache lines, unlike a 64 x 64 tile of 256-byte row pieces)
+  const long long n = (long long)job.R * job.C;
+  const long long base = (long long)(blockIdx.x - tile_start[j]) * 4096;
   float m = 0.f;
 #pragma unroll
-  for (int rr = 0; rr < 64; rr += 16) {
-    const int r = r0 + rr + ty, c = c0 + tx;
-    if (r < job.R) {
-      const float* src = job.src + (long long)r * job.C + c;
-      if (c + 3 < job.C && (job.C & 3) == 0) {
-        const f32x4 v = *(const f32x4*)src;
-        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-      } else {
-        for (int e = 0; e < 4 && c + e < job.C; ++e) m = fmaxf(m, fabsf(src[e]));
-      }
+  for (int it = 0; it < 4; ++it) {
+    const long long i = base + 4ll * (it * Q_THREADS + threadIdx.x);
+    if (i + 3 < n) {
+      const f32x4 v = *(const f32x4*)(job.src + i);
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    } else {
+      for (long long e = i; e < n; ++e) m = fmaxf(m, fabsf(job.src[e]));
     }
   }
   m = wave_max(m);

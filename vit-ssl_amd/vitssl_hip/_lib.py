@@ -48,6 +48,7 @@ PROTOTYPES = {
     "vitssl_gemm_bf16_tn": [_vp, _vp, _vp, _i64, _i, _i, _vp, _i64, _vp],
     "vitssl_gemm_fp8_nt": [C.POINTER(Gemm), C.POINTER(Fp8Gemm), _vp],
     "vitssl_quantize_fp8": [_vp, _vp, _i64, _vp],
+    "vitssl_attn_bwd_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "vitssl_quantize_fp8_scaled": [_vp, _vp, _i64, _vp, _vp, _vp],
     "vitssl_layernorm_bwd_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, Dropout, _i64, _i, _vp],
     "vitssl_grad_mask_cast_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, Dropout, _i64, _i, _vp],

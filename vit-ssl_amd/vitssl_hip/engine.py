@@ -572,8 +572,7 @@ class EncoderStack:
             # attention
             ops.gemm_fp8_nt(gm8, wot, dh_, L.EPI_BF16, alpha=ao, alpha2=inv(i, 2))
             ops.gemm_tn(gm, s["att"], gv(a_ + "final_linear.weight", (D, D)))
-            ops.attn_bwd(s["qkv"], s["att"], dh_, s["lse"], dqkv, delta, B, T, H, dh)
-            ops.quantize_fp8(dqkv, dq8, scale=sc(i, 3), amax=am(i, 3))
+            ops.attn_bwd(s["qkv"], s["att"], dh_, s["lse"], dqkv, delta, B, T, H, dh, dqkv_fp8=dq8, scale=sc(i, 3), amax=am(i, 3))
             settle(i, 3, dqkv, dq8)
             ops.gemm_fp8_nt(dq8, wqt, dh_, L.EPI_BF16, alpha=aq, alpha2=inv(i, 3))
             ops.gemm_tn(dqkv, s["h1"], st.span_view(a_ + "w_query.weight", a_ + "w_value.weight", (3 * D, D), grad=True))

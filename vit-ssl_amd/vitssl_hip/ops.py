@@ -273,9 +273,15 @@ def _attn_fwd(qkv, out, lse, B, N, H, dh, probs=None, out_fp8=None):
          _chk(lse, F32, "lse", (B, H, N)), _opt(probs, F32, "probs", (B, H, N, N)), B, N, H, dh, _stream())
 
 
-def attn_bwd(qkv, out, dout, lse, dqkv, delta_ws, B, N, H, dh):
+def attn_bwd(qkv, out, dout, lse, dqkv, delta_ws, B, N, H, dh, dqkv_fp8=None, scale=None, amax=None):
+    """`dqkv_fp8` (fp8 path): also the e4m3 image e4m3(dqkv * scale), with max|dqkv| recorded in `amax`."""
     ev = _prof_begin()
-    _attn_bwd(qkv, out, dout, lse, dqkv, delta_ws, B, N, H, dh)
+    if dqkv_fp8 is not None:
+        call("vitssl_attn_bwd_fp8", _chk(qkv, BF16, "qkv", (B * N, 3 * H * dh)), _chk(out, BF16, "out", (B * N, H * dh)),
+             _chk(dout, BF16, "dout", (B * N, H * dh)), _chk(lse, F32, "lse", (B, H, N)), _chk(dqkv, BF16, "dqkv", (B * N, 3 * H * dh)),
+             _chk(dqkv_fp8, FP8, "dqkv_fp8", (B * N, 3 * H * dh)), _scalar(scale, "scale"), _scalar(amax, "amax"), B, N, H, dh, _stream())
+    else:
+        _attn_bwd(qkv, out, dout, lse, dqkv, delta_ws, B, N, H, dh)
     _prof_end(ev, f"attn_bwd B{B} N{N} H{H}", 8.0 * B * H * N * N * dh)
 
 
