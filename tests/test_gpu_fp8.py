@@ -398,3 +398,29 @@ def test_vit_l_shaped_blocks_fp8(fp8_operands):
     with torch.no_grad():
         p32, _ = O.simmim_forward(sd, x, mask, 16, 16)
     assert rel_l2(pred, p32) < 8e-2                   # vs pure fp32: e4m3 operand rounding through two blocks
+
+
+def test_dino_step_with_fp8_operands():
+    """The DINO student / teacher backbones run on the same encoder stack: a fused step with e4m3 operands gives the
+    bf16 step's loss within the operand rounding, and keeps training."""
+    from vit_core.ssl.dino import DINOViT
+    from vit_core.ssl.dino.loss import DINOLoss
+    from vitssl_hip import engine
+    from vitssl_hip.optim import FusedAdamW
+    losses = {}
+    for mode in ("bf16", "fp8"):
+        engine.set_linear_operands(mode)
+        try:
+            torch.manual_seed(0)
+            model = DINOViT(num_blocks=2, input_shape=(3, 64, 64), embed_dim=128, patch_size=16, num_heads=2, mlp_dim=256,
+                            dropout=0.0, output_dim=512, center_momentum=0.9).to(DEV).train()
+            g = torch.Generator().manual_seed(3)
+            views = [torch.rand(4, 3, 64, 64, generator=g).to(DEV) for _ in range(2)] + [torch.rand(4, 3, 32, 32, generator=g).to(DEV) for _ in range(3)]
+            crit = DINOLoss(0.04, 0.1)
+            opt = FusedAdamW(model.trainable_store(), lr=1e-3, weight_decay=0.0)
+            ls = [float(model.train_step(views, 2, crit, opt, None, teacher_momentum=0.99)) for _ in range(4)]
+            losses[mode] = ls
+        finally:
+            engine.set_linear_operands("bf16")
+    assert all(l == l and l > 0 for l in losses["fp8"])
+    assert abs(losses["fp8"][0] - losses["bf16"][0]) < 5e-2 * abs(losses["bf16"][0])

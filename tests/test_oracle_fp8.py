@@ -81,3 +81,19 @@ def test_fp8_block_mode_sits_between_bf16_and_garbage():
     k2 = O.fp8_scale_exp(max(float(sd2[f"self_attention.{n}.weight"].abs().max()) for n in ("w_query", "w_key", "w_value")))
     assert k2 == O.fp8_scale_exp(64 * float(sd['self_attention.w_query.weight'].abs().max())) and k1 - k2 in (5, 6)
     assert math.isfinite(float(O.encoder_block(x, sd2, "", H, "fp8")[0].sum()))
+
+
+def test_engine_scale_rule_matches_the_oracle_rule():
+    """The host-side scale update of the fp8 engine (torch ops on device tensors; here on the CPU) follows the oracle's
+    exponent rule and produces exact powers of two."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vit-ssl_amd"))
+    from vitssl_hip.engine import EncoderStack
+    amax = torch.tensor([448.0, 449.0, 447.9, 224.0, 0.02, 1e-6, 3.0, 1.75, 1.7500001, 0.875, 6e-8, 1e30])
+    for margin in (0, 1):
+        got = EncoderStack._scale_from_amax(amax, margin)
+        want = torch.tensor([2.0 ** (O.fp8_scale_exp(float(a)) - margin) for a in amax])
+        assert torch.equal(got, want), (margin, got, want)
+        mant, _ = torch.frexp(got)
+        assert bool((mant == 0.5).all())
