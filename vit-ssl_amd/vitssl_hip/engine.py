@@ -110,6 +110,7 @@ class FlatStore:
         self._fp8: Dict[str, torch.Tensor] = {}
         self._fp8_jobs: List[Tuple[str, Callable[[], torch.Tensor]]] = []
         self._fp8_plan = None
+        self._fp8_index: Dict[str, int] = {}
 
     # ---- bookkeeping -------------------------------------------------------
     def is_attached(self) -> bool:
@@ -175,6 +176,7 @@ class FlatStore:
         """Declare a 2-D GEMM weight [N,K] whose GEMM operands are e4m3 images with a per-tensor power-of-two
         scale: `w8(key)` returns (image [N,K], dequantisation factor as a 1-element device tensor), `w8t(key)`
         the transposed image [K,N] (operand of the input-gradient GEMM) with the same factor."""
+        self._fp8_index[key] = len(self._fp8_jobs)
         self._fp8_jobs.append((key, src))
 
     def refresh_weights(self):
@@ -220,11 +222,11 @@ class FlatStore:
         return self._bf16[key]
 
     def w8(self, key: str) -> Tuple[torch.Tensor, torch.Tensor]:
-        j = next(i for i, (k8, _) in enumerate(self._fp8_jobs) if k8 == key)
+        j = self._fp8_index[key]
         return self._fp8[key], self._fp8_plan.alpha[j:j + 1]
 
     def w8t(self, key: str) -> Tuple[torch.Tensor, torch.Tensor]:
-        j = next(i for i, (k8, _) in enumerate(self._fp8_jobs) if k8 == key)
+        j = self._fp8_index[key]
         return self._fp8[key + ".T"], self._fp8_plan.alpha[j:j + 1]
 
 
