@@ -439,7 +439,9 @@ def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step, gscale=1.0):
 
 
 def ema(teacher, student, m):
+    ev = _prof_begin()
     call("vitssl_ema", _chk(teacher, F32, "teacher"), _chk(student, F32, "student", teacher.shape), teacher.numel(), float(m), _stream())
+    _prof_end(ev, "ema", 0.0, 12 * teacher.numel())               # teacher read + written, student read
 
 
 # ---- DINO ----------------------------------------------------------------------------
@@ -467,6 +469,13 @@ def weightnorm_bwd(dw, g, v, inv_vnorm, dg, dv):
 
 
 def dino_loss(teacher, student, center, t_ws, loss_sum, dstudent, G, V, B, K, teacher_temp, student_temp, gscale=1.0):
+    ev = _prof_begin()
+    _dino_loss(teacher, student, center, t_ws, loss_sum, dstudent, G, V, B, K, teacher_temp, student_temp, gscale)
+    # teacher / student logits read (fp32), teacher-probability scratch written + read, bf16 gradient written
+    _prof_end(ev, "dino_loss", 0.0, B * K * (4 * (G + V) + 8 + (2 * V if dstudent is not None else 0)))
+
+
+def _dino_loss(teacher, student, center, t_ws, loss_sum, dstudent, G, V, B, K, teacher_temp, student_temp, gscale=1.0):
     call("vitssl_dino_loss", _chk(teacher, F32, "teacher", (G * B, K)), _chk(student, F32, "student", (V * B, K)),
          _chk(center, F32, "center"), _chk(t_ws, F32, "t_ws", (B, K)), _chk(loss_sum, F32, "loss_sum", (1,)),
          _opt(dstudent, BF16, "dstudent", (V * B, K)), G, V, B, K, float(teacher_temp), float(student_temp), float(gscale), _stream())
@@ -474,7 +483,9 @@ def dino_loss(teacher, student, center, t_ws, loss_sum, dstudent, G, V, B, K, te
 
 def colsum_f32(x, out):
     rows, cols = x.shape
+    ev = _prof_begin()
     call("vitssl_colsum_f32", _chk(x, F32, "x"), _chk(out, F32, "out", (cols,)), rows, cols, _stream())
+    _prof_end(ev, "center_colsum", 0.0, 4 * rows * cols)
 
 
 def center_ema(center, colsum, momentum, inv_rows):
