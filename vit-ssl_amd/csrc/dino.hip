@@ -181,6 +181,104 @@ __global__ void dino_student_kernel(const float* __restrict__ student, const flo
   if (threadIdx.x == 0) atomicAdd(loss_sum, -acc * norm);
 }
 
+// Register-resident forms for K = 4096 * NV <= 65536 (the reference's K = 65536: NV = 16): 1024 threads hold one
+// whole row (NV float4 per thread), so every logit row is read from HBM ONCE instead of three times (the three-pass
+// kernels above re-read 256 KiB rows that 32 workgroups per XCD push out of the 4 MiB L2 in between).
+constexpr int DR_THREADS = 1024;
+
+__device__ __forceinline__ float block_reduce16(float v, float* red, bool is_max) {
+  v = is_max ? wave_max(v) : wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = red[0];
+#pragma unroll
+  for (int w = 1; w < DR_THREADS / 64; ++w) r = is_max ? fmaxf(r, red[w]) : r + red[w];
+  return r;
+}
+
+template <int NV>
+__global__ __launch_bounds__(DR_THREADS) void dino_teacher_reg_kernel(const float* __restrict__ teacher, const float* __restrict__ center,
+                                                                      float* __restrict__ T, int G, int B, int K, float inv_tau) {
+  __shared__ float red[DR_THREADS / 64];
+  const int b = blockIdx.x;
+#pragma unroll 1
+  for (int g = 0; g < G; ++g) {
+    const float* tr = teacher + ((long long)g * B + b) * K;
+    f32x4 x[NV];
+    float m = -INFINITY;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int k = 4 * (threadIdx.x + DR_THREADS * v);
+      x[v] = (*(const f32x4*)(tr + k) - *(const f32x4*)(center + k)) * inv_tau;
+      m = fmaxf(fmaxf(m, fmaxf(x[v][0], x[v][1])), fmaxf(x[v][2], x[v][3]));
+      if ((v & 3) == 3) asm volatile("" ::: "memory");   // at most 8 loads in flight: the row itself fills half the registers
+    }
+    m = block_reduce16(m, red, true);
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x[v][r] = __expf(x[v][r] - m);
+      s += (x[v][0] + x[v][1]) + (x[v][2] + x[v][3]);
+    }
+    s = block_reduce16(s, red, false);
+    const float inv = 1.0f / s;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int k = 4 * (threadIdx.x + DR_THREADS * v);
+      f32x4 p = x[v] * inv;
+      if (g > 0) p += *(const f32x4*)(T + (long long)b * K + k);
+      *(f32x4*)(T + (long long)b * K + k) = p;
+      if ((v & 3) == 3) asm volatile("" ::: "memory");   // keep at most 4 of the T loads in flight: the row already fills the registers
+    }
+  }
+}
+
+template <int NV>
+__global__ __launch_bounds__(DR_THREADS) void dino_student_reg_kernel(const float* __restrict__ student, const float* __restrict__ T,
+                                                                      float* __restrict__ loss_sum, bf16_t* __restrict__ dstudent, int G,
+                                                                      int B, int K, float inv_tau, float gscale) {
+  __shared__ float red[DR_THREADS / 64];
+  const long long row = blockIdx.x;
+  const int b = (int)(row % B);
+  const float* sr = student + row * K;
+  const float* tb = T + (long long)b * K;
+  f32x4 x[NV];
+  float m = -INFINITY;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    x[v] = *(const f32x4*)(sr + 4 * (threadIdx.x + DR_THREADS * v)) * inv_tau;
+    m = fmaxf(fmaxf(m, fmaxf(x[v][0], x[v][1])), fmaxf(x[v][2], x[v][3]));
+  }
+  m = block_reduce16(m, red, true);
+  float s = 0.f;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) s += (__expf(x[v][0] - m) + __expf(x[v][1] - m)) + (__expf(x[v][2] - m) + __expf(x[v][3] - m));
+  s = block_reduce16(s, red, false);
+  const float lse = m + __logf(s);
+  const float norm = 1.0f / ((float)G * (float)B * (float)K);
+  const float gs = gscale * inv_tau * norm;   // d loss / d logit = gs * (G * p - T)
+  float acc = 0.f;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int k = 4 * (threadIdx.x + DR_THREADS * v);
+    const f32x4 ls = x[v] - lse;              // log-softmax
+    const f32x4 t = *(const f32x4*)(tb + k);
+    acc += t[0] * ls[0] + t[1] * ls[1] + t[2] * ls[2] + t[3] * ls[3];
+    if (dstudent) {
+      float d[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) d[r] = gs * ((float)G * __expf(ls[r]) - t[r]);
+      u32x2 w = {pack_bf2(d[0], d[1]), pack_bf2(d[2], d[3])};
+      *(u32x2*)(dstudent + row * K + k) = w;
+    }
+    if ((v & 3) == 3) asm volatile("" ::: "memory");
+  }
+  acc = block_reduce16(acc, red, false);
+  if (threadIdx.x == 0) atomicAdd(loss_sum, -acc * norm);
+}
+
 // ---- centre --------------------------------------------------------------------------
 __global__ void colsum_f32_kernel(const float* __restrict__ x, float* __restrict__ out, long long rows, int cols) {
   const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -294,6 +392,22 @@ extern "C" int vitssl_dino_loss(const float* teacher, const float* student, cons
   VS_CHECK_ARG(G > 0 && V > 0 && B > 0 && K > 0 && K % 4 == 0, "dino_loss: K=%d must be a positive multiple of 4", K);
   VS_CHECK_ARG(teacher_temp > 0.f && student_temp > 0.f, "dino_loss: temperatures must be positive");
   hipStream_t s = (hipStream_t)stream;
+  const int nv = (K % 4096 == 0) ? K / 4096 : 0;
+#define VS_DINO_REG(NV)                                                                                                            \
+  do {                                                                                                                             \
+    hipLaunchKernelGGL(dino_teacher_reg_kernel<NV>, dim3(B), dim3(DR_THREADS), 0, s, teacher, center, t_ws, G, B, K, 1.0f / teacher_temp); \
+    VS_CHECK_LAUNCH("dino_teacher");                                                                                               \
+    hipLaunchKernelGGL(dino_student_reg_kernel<NV>, dim3(V * B), dim3(DR_THREADS), 0, s, student, t_ws, loss_sum,                     \
+                       (bf16_t*)dstudent_bf16, G, B, K, 1.0f / student_temp, gscale);                                              \
+    VS_CHECK_LAUNCH("dino_student");                                                                                               \
+    return VITSSL_OK;                                                                                                              \
+  } while (0)
+  if (nv == 16) VS_DINO_REG(16);
+  if (nv == 8) VS_DINO_REG(8);
+  if (nv == 4) VS_DINO_REG(4);
+  if (nv == 2) VS_DINO_REG(2);
+  if (nv == 1) VS_DINO_REG(1);
+#undef VS_DINO_REG
   hipLaunchKernelGGL(dino_teacher_kernel, dim3(B), dim3(DN_THREADS), 0, s, teacher, center, t_ws, G, B, K, 1.0f / teacher_temp);
   VS_CHECK_LAUNCH("dino_teacher");
   hipLaunchKernelGGL(dino_student_kernel, dim3(V * B), dim3(DN_THREADS), 0, s, student, t_ws, loss_sum, (bf16_t*)dstudent_bf16, G, B,
