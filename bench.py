@@ -187,7 +187,8 @@ def main():
         ones = torch.ones(1, device=dev)
         dist.all_reduce(ones)                               # what the collective library itself sees
         dp = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "allreduce_of_ones": float(ones),
-              "grad_bytes": 4 * store.gflat.numel(), "bucket_mb": reducer.bucket_elems * 4 / 2 ** 20}
+              "grad_bytes": 4 * store.gflat.numel(), "bucket_mb": reducer.bucket_elems * 4 / 2 ** 20,
+              "reserved_cus": int(os.environ.get("VITSSL_RESERVE_CUS", "0") or 0)}
         if float(ones) != world:
             raise SystemExit(f"all_reduce over {world} ranks returned {float(ones)}: the process group is not what torchrun launched")
     opt = FusedAdamW(store, lr=1e-4, weight_decay=1e-3)

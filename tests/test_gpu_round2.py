@@ -225,3 +225,35 @@ def test_wrong_device_index_is_refused():
         y = torch.empty(64, 64, dtype=torch.bfloat16, device="cuda:1")
         with pytest.raises(VitsslError, match="current device"):
             ops.cast_bf16(x, y)
+
+
+def test_reserved_cus_knob_keeps_results():
+    """VITSSL_RESERVE_CUS shrinks the persistent GEMM grids (CUs left to the collective library under data
+    parallelism); it is read once per process, so the check runs in a child process."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from vitssl_hip import _lib as L, ops
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+M, N, K = 3000, 768, 512
+A = torch.randn(M, K, device=dev).to(torch.bfloat16)
+B = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)
+out = torch.empty(M, N, device=dev)
+ops.gemm_nt(A, B, out, L.EPI_F32)
+ref = A.float() @ B.float().t()
+assert float((out - ref).norm() / ref.norm()) < 1e-5
+dY = torch.randn(M, 256, device=dev).to(torch.bfloat16)
+C = torch.zeros(256, K, device=dev)
+ops.gemm_tn(dY, A, C)
+ref = dY.float().t() @ A.float()
+assert float((C - ref).norm() / ref.norm()) < 1e-5
+print("ok")
+"""
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vit-ssl_amd")
+    env = dict(os.environ, VITSSL_RESERVE_CUS="24")
+    r = subprocess.run([sys.executable, "-c", code, pkg], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]

@@ -8,6 +8,10 @@
 
 // ---------------------------------------------------------------- error plumbing
 void vitssl_set_error(const char* fmt, ...);
+// CUs the persistent one-workgroup-per-CU GEMM grids may occupy: the device's CU count minus VITSSL_RESERVE_CUS
+// (default 0).  A collective library's kernels cannot co-reside with those workgroups (they take the whole register
+// file and 129 KiB of LDS of their CU), so under data parallelism a few CUs can be left to the all-reduce.
+int vitssl_persistent_cus(void);
 
 #define VS_CHECK_ARG(cond, ...)            \
   do {                                     \

@@ -1051,16 +1051,7 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_nt_pp_kernel(NtParams p)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-int cu_count() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-    if (n <= 0) n = 256;
-  }
-  return n;
-}
+int cu_count() { return vitssl_persistent_cus(); }
 
 // 1 (default): 8-wave BK = 64 tiles run the ping-pong kernel; 0: the two-phase loop (VITSSL_NT_PP, developer knob)
 int nt_pp_enabled() {
@@ -1239,6 +1230,22 @@ int launch_nt(const NtParams& p, hipStream_t s) {
 }
 
 }  // namespace
+
+int vitssl_persistent_cus(void) {
+  static int n = 0;
+  if (!n) {
+    int dev = 0, cus = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+    const char* e = getenv("VITSSL_RESERVE_CUS");
+    int reserve = e ? atoi(e) : 0;
+    if (reserve < 0) reserve = 0;
+    if (reserve > cus - 8) reserve = cus - 8;
+    n = cus - reserve;
+  }
+  return n;
+}
 
 #ifdef VITSSL_NT_STAMPS
 static unsigned long long* g_nt_stamps = nullptr;

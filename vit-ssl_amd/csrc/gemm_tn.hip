@@ -492,7 +492,7 @@ void tn_plan(long long M, int N1, int N2, int* tiles1, int* tiles2, int* splits,
   *tiles2 = (N2 + TN_T - 1) / TN_T;
   const long long total_chunks = (M + TN_KM - 1) / TN_KM;
   const int ntiles = *tiles1 * *tiles2;
-  long long sp = 256 / ntiles;                 // one round of the 256 CUs
+  long long sp = vitssl_persistent_cus() / ntiles;   // one round of the CUs this library may occupy
   if (sp < 1) sp = 1;
   if (sp > total_chunks) sp = total_chunks;
   *chunks_per_split = (int)((total_chunks + sp - 1) / sp);
