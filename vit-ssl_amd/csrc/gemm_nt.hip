@@ -113,6 +113,7 @@ struct NtParams {
   int k_chunk;   // split-K: K elements per blockIdx.y slice (0 = no split)
   int stagger;   // ping-pong kernel: estimated time of one output tile in 100 MHz ticks (0 = no start-up stagger)
   int esz;       // operand element size in bytes: 2 = bf16, 1 = fp8 e4m3 (ping-pong kernel only)
+  long long m_base;   // row of the whole problem that this launch's row 0 is (a problem split over two launches): dropout index only
   const float* alpha;   // fp8 operands: device scalar multiplied into the accumulators (product of the dequantisation scales), or NULL
   void* out2;    // fp8 operands: optional e4m3 image of out1 (EPI_GELU) / of out0 (EPI_DGELU) = the next GEMM's A operand, or NULL
   const float* alpha2;  // second device scalar multiplied into the accumulators (1 / scale of a scaled gradient operand), or NULL
@@ -398,7 +399,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             float mult[4] = {1.f, 1.f, 1.f, 1.f};
-            if (p.drop_on && NT_ABLATE != 2) drop_mult4(p.dk, (unsigned long long)(m * p.N + nn[jp][h]) >> 2, mult);
+            if (p.drop_on && NT_ABLATE != 2) drop_mult4(p.dk, (unsigned long long)((m + p.m_base) * p.N + nn[jp][h]) >> 2, mult);
             float y[4], d[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -449,7 +450,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
           for (int h = 0; h < 2; ++h) {
             if (p.drop_on && NT_ABLATE != 2) {
               float mult[4];
-              drop_mult4(p.dk, (unsigned long long)(m * p.N + nn[jp][h]) >> 2, mult);
+              drop_mult4(p.dk, (unsigned long long)((m + p.m_base) * p.N + nn[jp][h]) >> 2, mult);
               v[h][0] *= mult[0]; v[h][1] *= mult[1]; v[h][2] *= mult[2]; v[h][3] *= mult[3];
             }
             v[h] += res[ii][jp][h];
@@ -1224,8 +1225,66 @@ int launch_nt(const NtParams& p, hipStream_t s) {
   const double c256 = (double)ceil_div64(ceil_div64(p.M, 256) * tn, slots);
   const double c224 = 0.90 * (double)ceil_div64(ceil_div64(p.M, 224) * tn, slots);
   const double c192 = 0.78 * (double)ceil_div64(ceil_div64(p.M, 192) * tn, slots);
-  if (c192 < 0.9 * c256 && c192 <= c224) return launch_cfg<EPI, NtBig192>(p, s);
-  if (c224 < 0.95 * c256) return launch_cfg<EPI, NtBig224>(p, s);
+  double best = c256;
+  if (c192 < 0.9 * c256 && c192 <= c224) best = c192;
+  else if (c224 < 0.95 * c256) best = c224;
+  // Two launches over disjoint row ranges: the first fills whole tile rounds with one tile height, the second
+  // finishes the remaining rows in ONE round with another height, so no round runs with most CUs idle
+  // (M = 50176, N = 768: 672 tiles of 224 rows = 2.6 rounds at cost 2.7; 2 full rounds of 192-row tiles + one
+  // round of 224-row tiles cost 2 x 0.78 + 0.9 = 2.46).  Row ranges only move base pointers; the dropout
+  // stream is indexed by the row of the whole problem (m_base).
+  if constexpr (EPI != VITSSL_EPI_EMBED && EPI != EPI_F32_SPLITK) {
+    // Default OFF: measured 36.95 / 36.88 -> 36.82 / 36.83 ms per ViT-B step (0.3 %).  The ping-pong loop is bound by
+    // the bytes it stages, (rows + 256) per K-tile, so a 192-row tile costs 0.875 of a 256-row one, not 0.78 as the
+    // round-1 loop did, and the second launch has its own prologue: most of the tail's 8 % goes back into smaller tiles.
+    static int split_knob = -1;                          // VITSSL_NT_ROWSPLIT=1 enables (developer knob)
+    if (split_knob < 0) {
+      const char* e = getenv("VITSSL_NT_ROWSPLIT");
+      split_knob = e ? atoi(e) : 0;
+    }
+    static const int heights[3] = {256, 224, 192};
+    static const double costs[3] = {1.0, 0.90, 0.78};
+    int bx = -1, by = -1;
+    long long brows = 0;
+    double bcost = best * 0.97;                          // must beat the single launch by 3 %
+    if (split_knob && p.k_chunk == 0) {
+      for (int x = 0; x < 3; ++x) {
+        const long long per_round = slots / tn;          // tile rows of height x per full round
+        if (per_round < 1) continue;
+        const long long rounds = (p.M / heights[x]) / per_round;   // full rounds of x-tiles that fit
+        for (long long r = rounds; r >= 1 && r >= rounds - 1; --r) {
+          const long long rows_x = r * per_round * heights[x];
+          const long long rest = p.M - rows_x;
+          if (rest <= 0) continue;
+          for (int y = 0; y < 3; ++y) {
+            if (ceil_div64(rest, heights[y]) * tn > slots) continue;
+            const double c = (double)r * costs[x] + costs[y];
+            if (c < bcost) { bcost = c; bx = x; by = y; brows = rows_x; }
+          }
+        }
+      }
+    }
+    if (bx >= 0) {
+      NtParams a = p, b = p;
+      a.M = brows;
+      b.M = p.M - brows;
+      b.m_base = p.m_base + brows;
+      const long long ea = (long long)p.K * p.esz;
+      b.A = (const bf16_t*)((const char*)p.A + brows * ea);
+      const int e0 = (EPI == VITSSL_EPI_F32 || EPI == VITSSL_EPI_RESID) ? 4 : 2;
+      b.out0 = (char*)p.out0 + brows * (long long)p.N * e0;
+      if (p.out1) b.out1 = (char*)p.out1 + brows * (long long)p.N * 2;
+      if (p.out2) b.out2 = (char*)p.out2 + brows * (long long)p.N;
+      if (p.aux) b.aux = (const char*)p.aux + brows * (long long)p.N * (EPI == VITSSL_EPI_RESID ? 4 : 2);
+      auto go = [&](int h, const NtParams& q) {
+        return h == 0 ? launch_cfg<EPI, NtBig>(q, s) : (h == 1 ? launch_cfg<EPI, NtBig224>(q, s) : launch_cfg<EPI, NtBig192>(q, s));
+      };
+      if (int rc = go(bx, a)) return rc;
+      return go(by, b);
+    }
+  }
+  if (best == c192 && best != c256) return launch_cfg<EPI, NtBig192>(p, s);
+  if (best == c224 && best != c256) return launch_cfg<EPI, NtBig224>(p, s);
   return launch_cfg<EPI, NtBig>(p, s);
 }
 
@@ -1279,6 +1338,7 @@ static int gemm_nt_entry(const vitssl_gemm_t* g, int esz, const vitssl_fp8_gemm_
   p.k_chunk = 0;
   p.stagger = 0;
   p.esz = esz;
+  p.m_base = 0;
   p.alpha = q ? q->alpha : nullptr;
   p.alpha2 = q ? q->alpha2 : nullptr;
   p.out2 = q ? q->out_fp8 : nullptr;
