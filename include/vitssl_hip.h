@@ -137,6 +137,12 @@ int vitssl_gemm_fp8_nt(const vitssl_gemm_t* g, const vitssl_fp8_gemm_t* q, void*
 /* vitssl_attn_fwd that also writes the e4m3 image of `out` (made from the fp32 values before the bf16 store) */
 int vitssl_attn_fwd_fp8(const void* qkv, void* out, void* out_fp8, float* lse, float* probs, int B, int N, int H, int dh,
                         void* stream);
+/* Weight gradient on e4m3 operands: C[N1,N2] (fp32) += alpha * alpha2 * A8[M,N1]^T . B8[M,N2]  (dY scaled image x the
+ * unit-scale activation image; transposed 1-byte LDS reads, v_mfma_f32_16x16x128_f8f6f4).  N1 % 16 == 0, N2 % 16 == 0;
+ * workspace as for vitssl_gemm_bf16_tn (its size from vitssl_gemm_fp8_tn_workspace_floats). */
+int64_t vitssl_gemm_fp8_tn_workspace_floats(int64_t M, int N1, int N2);
+int vitssl_gemm_fp8_tn(const void* A8, const void* B8, float* C, int64_t M, int N1, int N2, const float* alpha,
+                       const float* alpha2, float* workspace, int64_t workspace_floats, void* stream);
 /* vitssl_attn_bwd (one-launch form) that also writes dqkv_fp8 = e4m3(dqkv * *qscale) and records max|dqkv| in *qamax */
 int vitssl_attn_bwd_fp8(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, void* dqkv_fp8,
                         const float* qscale, float* qamax, int B, int N, int H, int dh, void* stream);

@@ -19,8 +19,8 @@ Two modes:
     weight path"): activations quantised at unit scale (saturating at +-448),
     weights per tensor with the power-of-two scale 2^floor(log2(448 / max|w|)),
     fp32 accumulation.  With the gradient scales the HIP engine exports
-    (``fp8_gscales``) the input-gradient products dX = dY.W run on e4m3 operands as
-    well (dY quantised with that per-tensor scale); weight gradients use bf16 operands.  The reference has no fp8 code: this mode restates the HIP design,
+    (``fp8_gscales``) the backward products dX = dY.W and dW = dY^T.X run on e4m3
+    operands as well (dY quantised with that per-tensor scale).  The reference has no fp8 code: this mode restates the HIP design,
     and is tied to the reference only through its fp32 / bf16 siblings.
 
 Pinned against fixtures generated from the reference (tests/golden).
@@ -79,8 +79,9 @@ def fp8_scale_exp(amax: float) -> int:
 
 
 class _LinearFP8(torch.autograd.Function):
-    """y = (q8(x) . q8(w 2^k)^T) 2^-k in the forward.  Backward: the weight gradient takes bf16(x); the input
-    gradient takes bf16(w), or -- with a gradient scale s (fp8 input-gradient GEMMs) -- q8(g s) . q8(w 2^k) 2^-k / s."""
+    """y = (q8(x) . q8(w 2^k)^T) 2^-k in the forward.  Backward without a gradient scale: bf16 operands (g . bf16(w),
+    g^T . bf16(x)).  With a gradient scale s (the HIP fp8 path): both products on e4m3 operands,
+    dX = q8(g s) . q8(w 2^k) 2^-k / s and dW = q8(g s)^T . q8(x) / s."""
 
     @staticmethod
     def forward(ctx, x32, w, k, via_bf16, gscale):
@@ -88,18 +89,20 @@ class _LinearFP8(torch.autograd.Function):
         wb = w.to(torch.bfloat16).to(torch.float32)
         x8 = q8(xb if via_bf16 else x32)
         w8 = q8(w * (2.0 ** k))
-        ctx.save_for_backward(xb, wb, w8)
+        ctx.save_for_backward(xb, wb, w8, x8)
         ctx.k, ctx.gscale = k, gscale
         return (x8 @ w8.t()) * (2.0 ** -k)
 
     @staticmethod
     def backward(ctx, g):
-        xb, wb, w8 = ctx.saved_tensors
+        xb, wb, w8, x8 = ctx.saved_tensors
         if ctx.gscale is None:
             gx = g @ wb
+            gw = g.reshape(-1, g.shape[-1]).t() @ xb.reshape(-1, xb.shape[-1])
         else:
-            gx = (q8(g * ctx.gscale) @ w8) * ((2.0 ** -ctx.k) / ctx.gscale)
-        gw = g.reshape(-1, g.shape[-1]).t() @ xb.reshape(-1, xb.shape[-1])
+            g8 = q8(g * ctx.gscale)
+            gx = (g8 @ w8) * ((2.0 ** -ctx.k) / ctx.gscale)
+            gw = (g8.reshape(-1, g.shape[-1]).t() @ x8.reshape(-1, x8.shape[-1])) / ctx.gscale
         return gx, gw, None, None, None
 
 

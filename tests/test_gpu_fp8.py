@@ -283,6 +283,24 @@ def test_gemm_fp8_dgelu_with_scaled_image(M, N, K):
     assert float(same) > 0.99
 
 
+@pytest.mark.parametrize("M,N1,N2", [(300, 128, 128), (1000, 384, 256), (4100, 768, 272), (25088, 1024, 1024)])
+def test_gemm_fp8_tn_weight_gradient(M, N1, N2):
+    """C += alpha alpha2 A8^T B8: exact e4m3 products, fp32 accumulation -- against an fp64 product of the same bytes."""
+    from vitssl_hip import ops
+    torch.manual_seed(M + N1)
+    A = _q8_torch(torch.randn(M, N1) * 3).to(DEV)
+    B = _q8_torch(torch.randn(M, N2) * 2).to(DEV)
+    C0 = torch.randn(N1, N2)
+    Cd = C0.clone().to(DEV)
+    alpha, alpha2 = torch.tensor([2.0 ** -5], device=DEV), torch.tensor([0.75], device=DEV)
+    ops.gemm_fp8_tn(A, B, Cd, alpha=alpha, alpha2=alpha2)
+    ref = C0.double() + (A.cpu().float().double().t() @ B.cpu().float().double()) * (2.0 ** -5 * 0.75)
+    assert rel_l2(Cd, ref) < 2e-5
+    Cd2 = torch.zeros(N1, N2, device=DEV)
+    ops.gemm_fp8_tn(A, B, Cd2)                       # no scalars
+    assert rel_l2(Cd2, A.cpu().float().double().t() @ B.cpu().float().double()) < 2e-5
+
+
 def test_gemm_fp8_rejects_bad_arguments():
     from vitssl_hip import _lib as L, ops
     A = torch.zeros(64, 192, dtype=FP8, device=DEV)

@@ -478,6 +478,171 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_pp_kernel(TnParams p) {
   }
 }
 
+// ====================================================================================
+// Weight gradient on e4m3 operands (fp8 path):  C[N1,N2] += alpha * A8[M,N1]^T . B8[M,N2].
+// A K-tile is 128 contraction rows of 256 one-byte columns (32 KiB per operand, the bf16 tile's bytes); a lane's
+// operand of v_mfma_f32_16x16x128_f8f6f4 -- 32 k-values of one column -- is four ds_read_b64_tr_b8 (each hands a lane
+// column (lane & 15) of 8 rows; lane i of a 16-lane group addresses the 8-byte half i & 1 of row i >> 1).  Lane group g
+// takes rows 32 g + 8 q + 0..7 in read q: the same k order for both operands, which is all a contraction needs.
+// The 16-byte chunk index is XORed with f(row) = (row & 7) | ((row >> 5) & 1) << 3 on the DMA source side and on the
+// reads: the two lane groups of a half-wave then touch 16 rows x 16 B in 16 distinct chunk positions (conflict-free).
+// Plain double buffering, all 8 waves in step: one K = 128 MFMA step consumes the whole tile, so the half-tile units of
+// the ping-pong schedule (refilled two phases after their last read) do not exist here; the next tile's DMA is in
+// flight under the current tile's 48 reads and 32 MFMAs per wave.
+struct Tn8Params {
+  const unsigned char* A;
+  const unsigned char* B;
+  float* C;
+  long long M;
+  int N1, N2;
+  int tiles1, tiles2, splits;
+  int chunks_per_split;   // in units of TN8_KM rows
+  float* slabs;
+  const float* alpha;     // device scalars multiplied into the result (dequantisation of the two operands), or NULL
+  const float* alpha2;
+};
+constexpr int TN8_KM = 128;
+typedef __attribute__((ext_vector_type(2))) int tn_i32x2;
+
+__device__ __forceinline__ int tn8_f(int row) { return (row & 7) | (((row >> 5) & 1) << 3); }
+
+template <int IMM>
+__device__ __forceinline__ void tn8_ds_tr(tn_i32x2& dst, unsigned addr) {
+  asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(IMM));
+}
+
+__global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_fp8_kernel(Tn8Params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BUF = 2 * TN_TILE_BYTES;               // one K-tile: A tile then B tile
+  constexpr unsigned OOBV = 0x80000000u;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int w1 = wave >> 2, w2 = wave & 3;
+
+  const int ntiles = p.tiles1 * p.tiles2;
+  const int nwg = ntiles * p.splits;
+  const int xcd = blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7;
+  const int bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
+  const int split = bid / ntiles;
+  const int tile = bid - split * ntiles;
+  const int t1 = tile / p.tiles2, t2 = tile - t1 * p.tiles2;
+  const int c1 = t1 * TN_T, c2 = t2 * TN_T;
+
+  const long long total_chunks = (p.M + TN8_KM - 1) / TN8_KM;
+  const long long ch_begin = (long long)split * p.chunks_per_split;
+  long long ch_end = ch_begin + p.chunks_per_split;
+  if (ch_end > total_chunks) ch_end = total_chunks;
+  const int nk = ch_begin < ch_end ? (int)(ch_end - ch_begin) : 0;   // empty split: writes a zero slab
+
+  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((unsigned long long)p.M * p.N1), 0x00020000);
+  __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)((unsigned long long)p.M * p.N2), 0x00020000);
+
+  // staging: instruction slot e of this wave covers tile rows 16 wave + 4 e + (lane >> 4), one 16-byte chunk per lane
+  unsigned voffA[4], voffB[4];
+  int ldsoff[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int r0 = 16 * wave + 4 * e;
+    const int row = r0 + (lane >> 4);
+    const int sch = (lane & 15) ^ tn8_f(row);
+    const bool ok1 = c1 + sch * 16 < p.N1, ok2 = c2 + sch * 16 < p.N2;     // columns past the matrix: zero fill
+    voffA[e] = ok1 ? (unsigned)(row * (long long)p.N1 + c1 + sch * 16) : OOBV;
+    voffB[e] = ok2 ? (unsigned)(row * (long long)p.N2 + c2 + sch * 16) : OOBV;
+    ldsoff[e] = r0 * 256;
+  }
+  const unsigned stepA = (unsigned)TN8_KM * (unsigned)p.N1, stepB = (unsigned)TN8_KM * (unsigned)p.N2;
+  auto stage = [&](int t, int bufsel) {
+    const unsigned ba = (unsigned)(ch_begin + t) * stepA, bb = (unsigned)(ch_begin + t) * stepB;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      tn_dma16(rsA, smem + bufsel * BUF + ldsoff[e], voffA[e] == OOBV ? OOBV : voffA[e] + ba);
+      tn_dma16(rsB, smem + bufsel * BUF + TN_TILE_BYTES + ldsoff[e], voffB[e] == OOBV ? OOBV : voffB[e] + bb);
+    }
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // per-lane byte address of read 0 (rows 32 g + (i >> 1)) of every 16-column tile; read q adds 8 rows = 2048 bytes
+  // (f(row + 8 q) = f(row) for q < 4: bits 3 and 4 of the row do not enter f)
+  const unsigned lds0 = (unsigned)(unsigned long long)LDS_PTR(smem);
+  unsigned fragA[8], fragB[4];
+  {
+    const int g = lane >> 4, i16 = lane & 15;
+    const int r0 = 32 * g + (i16 >> 1);
+    const int fx = tn8_f(r0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fragA[i] = lds0 + r0 * 256 + (((w1 * 8 + i) ^ fx) << 4) + 8 * (i16 & 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fragB[j] = lds0 + TN_TILE_BYTES + r0 * 256 + (((w2 * 4 + j) ^ fx) << 4) + 8 * (i16 & 1);
+  }
+
+  if (nk > 0) stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int t = 0; t < nk; ++t) {
+    const unsigned cur = (unsigned)((t & 1) * BUF);
+    if (t + 1 < nk) stage(t + 1, (t + 1) & 1);
+    tn_i32x2 rb[4][4], ra[8][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      tn8_ds_tr<0>(rb[j][0], fragB[j] + cur);
+      tn8_ds_tr<2048>(rb[j][1], fragB[j] + cur);
+      tn8_ds_tr<4096>(rb[j][2], fragB[j] + cur);
+      tn8_ds_tr<6144>(rb[j][3], fragB[j] + cur);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      tn8_ds_tr<0>(ra[i][0], fragA[i] + cur);
+      tn8_ds_tr<2048>(ra[i][1], fragA[i] + cur);
+      tn8_ds_tr<4096>(ra[i][2], fragA[i] + cur);
+      tn8_ds_tr<6144>(ra[i][3], fragA[i] + cur);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    i32x8 fb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      fb[j] = i32x8{rb[j][0][0], rb[j][0][1], rb[j][1][0], rb[j][1][1], rb[j][2][0], rb[j][2][1], rb[j][3][0], rb[j][3][1]};
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const i32x8 fa = {ra[i][0][0], ra[i][0][1], ra[i][1][0], ra[i][1][1], ra[i][2][0], ra[i][2][1], ra[i][3][0], ra[i][3][1]};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb[j], fa, acc[i][j], 0, 0, 0, 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  const float al = (p.alpha ? *p.alpha : 1.0f) * (p.alpha2 ? *p.alpha2 : 1.0f);
+  float* dst = p.slabs ? p.slabs + (long long)split * p.N1 * p.N2 : p.C;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int n1 = c1 + w1 * 128 + i * 16 + (lane & 15);
+    if (n1 >= p.N1) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n2 = c2 + w2 * 64 + j * 16 + 4 * (lane >> 4);
+      if (n2 >= p.N2) continue;
+      float* q = dst + (long long)n1 * p.N2 + n2;
+      const f32x4 v = acc[i][j] * al;
+      if (p.slabs) {
+        *(f32x4*)q = v;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) unsafeAtomicAdd(q + r, v[r]);
+      }
+    }
+  }
+}
+
 // C[e] += sum_s slabs[s][e]
 __global__ void tn_reduce_kernel(float* __restrict__ C, const float* __restrict__ slabs, long long n4, long long stride, int splits) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
@@ -487,10 +652,10 @@ __global__ void tn_reduce_kernel(float* __restrict__ C, const float* __restrict_
   }
 }
 
-void tn_plan(long long M, int N1, int N2, int* tiles1, int* tiles2, int* splits, int* chunks_per_split) {
+void tn_plan(long long M, int N1, int N2, int* tiles1, int* tiles2, int* splits, int* chunks_per_split, int km = TN_KM) {
   *tiles1 = (N1 + TN_T - 1) / TN_T;
   *tiles2 = (N2 + TN_T - 1) / TN_T;
-  const long long total_chunks = (M + TN_KM - 1) / TN_KM;
+  const long long total_chunks = (M + km - 1) / km;
   const int ntiles = *tiles1 * *tiles2;
   long long sp = vitssl_persistent_cus() / ntiles;   // one round of the CUs this library may occupy
   if (sp < 1) sp = 1;
@@ -554,6 +719,55 @@ extern "C" int vitssl_gemm_bf16_tn(const void* A, const void* B, float* C, int64
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, s, C, p.slabs, n4, (long long)N1 * N2, p.splits);
     VS_CHECK_LAUNCH("gemm_tn_reduce");
+  }
+  return VITSSL_OK;
+}
+
+extern "C" int64_t vitssl_gemm_fp8_tn_workspace_floats(int64_t M, int N1, int N2) {
+  if (M <= 0 || N1 <= 0 || N2 <= 0) return 0;
+  int t1, t2, sp, cps;
+  tn_plan(M, N1, N2, &t1, &t2, &sp, &cps, TN8_KM);
+  return (int64_t)sp * N1 * N2;
+}
+
+extern "C" int vitssl_gemm_fp8_tn(const void* A8, const void* B8, float* C, int64_t M, int N1, int N2, const float* alpha,
+                                  const float* alpha2, float* workspace, int64_t workspace_floats, void* stream) {
+  VS_CHECK_ARG(A8 && B8 && C, "gemm_fp8_tn: null operand");
+  VS_CHECK_ARG(M > 0 && N1 > 0 && N2 > 0, "gemm_fp8_tn: empty problem");
+  VS_CHECK_ARG(N1 % 16 == 0 && N2 % 16 == 0, "gemm_fp8_tn: N1=%d N2=%d must be multiples of 16", N1, N2);
+  VS_CHECK_ARG((unsigned long long)M * N1 < (1ull << 31) && (unsigned long long)M * N2 < (1ull << 31),
+               "gemm_fp8_tn: operand larger than 2 GiB");
+  Tn8Params p;
+  p.A = (const unsigned char*)A8;
+  p.B = (const unsigned char*)B8;
+  p.C = C;
+  p.M = M;
+  p.N1 = N1;
+  p.N2 = N2;
+  p.alpha = alpha;
+  p.alpha2 = alpha2;
+  tn_plan(M, N1, N2, &p.tiles1, &p.tiles2, &p.splits, &p.chunks_per_split, TN8_KM);
+  const long long need = (long long)p.splits * N1 * N2;
+  p.slabs = (workspace && workspace_floats >= need) ? workspace : nullptr;
+  VS_CHECK_ARG(!workspace || p.slabs, "gemm_fp8_tn: workspace too small (%lld < %lld floats)", (long long)workspace_floats, need);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_fp8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
+    if (e != hipSuccess) {
+      vitssl_set_error("gemm_fp8_tn: cannot raise dynamic LDS: %s", hipGetErrorString(e));
+      return VITSSL_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gemm_tn_fp8_kernel, dim3(p.tiles1 * p.tiles2 * p.splits), dim3(TN_THREADS), TN_LDS_BYTES, s, p);
+  VS_CHECK_LAUNCH("gemm_fp8_tn");
+  if (p.slabs) {
+    const long long n4 = (long long)N1 * N2 / 4;
+    long long grid = (n4 + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, s, C, p.slabs, n4, (long long)N1 * N2, p.splits);
+    VS_CHECK_LAUNCH("gemm_fp8_tn_reduce");
   }
   return VITSSL_OK;
 }

@@ -47,6 +47,7 @@ PROTOTYPES = {
     "vitssl_gemm_bf16_nt": [C.POINTER(Gemm), _vp],
     "vitssl_gemm_bf16_tn": [_vp, _vp, _vp, _i64, _i, _i, _vp, _i64, _vp],
     "vitssl_gemm_fp8_nt": [C.POINTER(Gemm), C.POINTER(Fp8Gemm), _vp],
+    "vitssl_gemm_fp8_tn": [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _i64, _vp],
     "vitssl_quantize_fp8": [_vp, _vp, _i64, _vp],
     "vitssl_attn_bwd_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "vitssl_quantize_fp8_scaled": [_vp, _vp, _i64, _vp, _vp, _vp],
@@ -117,6 +118,8 @@ def lib():
     l.vitssl_version.argtypes = []
     l.vitssl_gemm_tn_workspace_floats.restype = C.c_int64
     l.vitssl_gemm_tn_workspace_floats.argtypes = [C.c_int64, C.c_int, C.c_int]
+    l.vitssl_gemm_fp8_tn_workspace_floats.restype = C.c_int64
+    l.vitssl_gemm_fp8_tn_workspace_floats.argtypes = [C.c_int64, C.c_int, C.c_int]
     l.vitssl_embed_bwd_workspace_floats.restype = C.c_int64
     l.vitssl_embed_bwd_workspace_floats.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     for name, args in PROTOTYPES.items():

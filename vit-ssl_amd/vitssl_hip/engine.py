@@ -408,17 +408,19 @@ class EncoderStack:
             ln2 = (xmid, st.view(self._n(i, "layer_norm2.weight")), st.view(self._n(i, "layer_norm2.bias")))
             b1, b2 = st.view(self._n(i, "feed_forward.linear_in.bias")), st.view(self._n(i, "feed_forward.linear_out.bias"))
             if self.fp8:
-                # forward products on e4m3 operands: every producer also writes the e4m3 image of its output (transient,
-                # shared by all blocks); the bf16 images are still saved for the backward's weight-gradient GEMMs
-                x8 = g(f"{slot}.q8.d", (M, D), FP8, dev)
-                a8 = g(f"{slot}.q8.f", (M, F), FP8, dev)
+                # products on e4m3 operands: every producer also writes the e4m3 image of its output, kept per block for
+                # the weight-gradient GEMMs of the backward (one byte per element next to the bf16 images)
+                h1_8 = g(tag + "h1_8", (M, D), FP8, dev)
+                att8 = g(tag + "att8", (M, D), FP8, dev)
+                h2_8 = g(tag + "h2_8", (M, D), FP8, dev)
+                a8 = g(tag + "a8", (M, F), FP8, dev)
                 (wq, aq), (wo, ao), (w1, a1), (w2, a2) = (st.w8(self._n(i, k)) for k in ("wqkv", "wo", "w1", "w2"))
-                ops.layernorm_fwd_fp8(*ln1, h1, x8, mean1, rstd1)
-                ops.gemm_fp8_nt(x8, wq, qkv, L.EPI_BF16, alpha=aq)
-                ops.attn_fwd(qkv, att, lse, B, T, H, dh, probs=probs if i == self.L - 1 else None, out_fp8=x8)
-                ops.gemm_fp8_nt(x8, wo, xmid, L.EPI_RESID, alpha=ao, aux=cur, drop=self._drop(i, 0, seed, training))
-                ops.layernorm_fwd_fp8(*ln2, h2, x8, mean2, rstd2)
-                ops.gemm_fp8_nt(x8, w1, u, L.EPI_GELU, alpha=a1, bias=b1, out1=a, out_fp8=a8, drop=self._drop(i, 1, seed, training))
+                ops.layernorm_fwd_fp8(*ln1, h1, h1_8, mean1, rstd1)
+                ops.gemm_fp8_nt(h1_8, wq, qkv, L.EPI_BF16, alpha=aq)
+                ops.attn_fwd(qkv, att, lse, B, T, H, dh, probs=probs if i == self.L - 1 else None, out_fp8=att8)
+                ops.gemm_fp8_nt(att8, wo, xmid, L.EPI_RESID, alpha=ao, aux=cur, drop=self._drop(i, 0, seed, training))
+                ops.layernorm_fwd_fp8(*ln2, h2, h2_8, mean2, rstd2)
+                ops.gemm_fp8_nt(h2_8, w1, u, L.EPI_GELU, alpha=a1, bias=b1, out1=a, out_fp8=a8, drop=self._drop(i, 1, seed, training))
                 ops.gemm_fp8_nt(a8, w2, xout, L.EPI_RESID, alpha=a2, bias=b2, aux=xmid, drop=self._drop(i, 2, seed, training))
             else:
                 ops.layernorm_fwd(*ln1, h1, mean1, rstd1)
@@ -431,6 +433,8 @@ class EncoderStack:
             if save:
                 rec["blocks"].append(dict(xin=cur, h1=h1, mean1=mean1, rstd1=rstd1, qkv=qkv, att=att, lse=lse, xmid=xmid,
                                           h2=h2, mean2=mean2, rstd2=rstd2, u=u, a=a))
+                if self.fp8:
+                    rec["blocks"][-1].update(h1_8=h1_8, att8=att8, h2_8=h2_8, a8=a8)
             cur = xout
         if save:
             self._saved[slot] = rec
@@ -524,10 +528,9 @@ class EncoderStack:
         self._gs_valid = False
 
     def _backward_fp8(self, g: torch.Tensor, slot: str, reducer: Optional[GradReducer]) -> torch.Tensor:
-        """The schedule of backward() with the four input-gradient GEMMs of every block on e4m3 operands: the
-        transposed weight images of the store, and gradient images written by the producers of the gradients
-        (LayerNorm backward, the dGELU epilogue, a quantising pass over dQKV) next to the bf16 images the
-        weight-gradient GEMMs keep reading."""
+        """The schedule of backward() with all eight backward GEMMs of every block on e4m3 operands: the transposed
+        weight images of the store, the activation images saved by the forward, and gradient images written by the
+        producers of the gradients (LayerNorm backward, the dGELU epilogue, the attention backward's store phase)."""
         st, D, H, F, dh = self.store, self.D, self.H, self.F, self.dh
         rec = self._saved[slot]
         B, T, seed, training = rec["B"], rec["T"], rec["seed"], rec["training"]
@@ -564,20 +567,21 @@ class EncoderStack:
             ops.gemm_fp8_nt(gm8, w2t, du, L.EPI_DGELU, alpha=a2, alpha2=inv(i, 0), aux=s["u"],
                             colsum=gv(self._n(i, "feed_forward.linear_in.bias")), out_fp8=du8, out_scale=sc(i, 1), out_amax=am(i, 1))
             settle(i, 1, du, du8)
-            ops.gemm_tn(gm, s["a"], gv(self._n(i, "feed_forward.linear_out.weight"), (D, F)))
+            ops.gemm_fp8_tn(gm8, s["a8"], gv(self._n(i, "feed_forward.linear_out.weight"), (D, F)), alpha2=inv(i, 0))
             ops.gemm_fp8_nt(du8, w1t, dh_, L.EPI_BF16, alpha=a1, alpha2=inv(i, 1))
-            ops.gemm_tn(du, s["h2"], gv(self._n(i, "feed_forward.linear_in.weight"), (F, D)))
+            ops.gemm_fp8_tn(du8, s["h2_8"], gv(self._n(i, "feed_forward.linear_in.weight"), (F, D)), alpha2=inv(i, 1))
             ops.layernorm_bwd_fp8(dh_, s["xmid"], s["mean2"], s["rstd2"], st.view(self._n(i, "layer_norm2.weight")), g, g, gm, gm8,
                                   sc(i, 2), am(i, 2), gv(self._n(i, "layer_norm2.weight")), gv(self._n(i, "layer_norm2.bias")), None,
                                   self._drop(i, 0, seed, training))
             settle(i, 2, gm, gm8)
             # attention
             ops.gemm_fp8_nt(gm8, wot, dh_, L.EPI_BF16, alpha=ao, alpha2=inv(i, 2))
-            ops.gemm_tn(gm, s["att"], gv(a_ + "final_linear.weight", (D, D)))
+            ops.gemm_fp8_tn(gm8, s["att8"], gv(a_ + "final_linear.weight", (D, D)), alpha2=inv(i, 2))
             ops.attn_bwd(s["qkv"], s["att"], dh_, s["lse"], dqkv, delta, B, T, H, dh, dqkv_fp8=dq8, scale=sc(i, 3), amax=am(i, 3))
             settle(i, 3, dqkv, dq8)
             ops.gemm_fp8_nt(dq8, wqt, dh_, L.EPI_BF16, alpha=aq, alpha2=inv(i, 3))
-            ops.gemm_tn(dqkv, s["h1"], st.span_view(a_ + "w_query.weight", a_ + "w_value.weight", (3 * D, D), grad=True))
+            ops.gemm_fp8_tn(dq8, s["h1_8"], st.span_view(a_ + "w_query.weight", a_ + "w_value.weight", (3 * D, D), grad=True),
+                            alpha2=inv(i, 3))
             if i > 0:
                 ops.layernorm_bwd_fp8(dh_, s["xin"], s["mean1"], s["rstd1"], st.view(self._n(i, "layer_norm1.weight")), g, g, gm, gm8,
                                       sc(i - 1, 0), am(i - 1, 0), gv(self._n(i, "layer_norm1.weight")), gv(self._n(i, "layer_norm1.bias")),

@@ -257,6 +257,21 @@ def gemm_tn(A, B, Cacc, atomic=False):
     _prof_end(ev, f"gemm_tn {N1}x{N2}x{M}", 2.0 * M * N1 * N2)
 
 
+def gemm_fp8_tn(A8, B8, Cacc, alpha=None, alpha2=None):
+    """Cacc[N1,N2] (fp32) += alpha * alpha2 * A8[M,N1]^T @ B8[M,N2] on e4m3 operands (weight gradient of the fp8 path)."""
+    M, N1 = A8.shape
+    M2, N2 = B8.shape
+    if M != M2:
+        raise L.VitsslError(f"gemm_fp8_tn: M mismatch {M} vs {M2}")
+    a, b, c = _chk(A8, FP8, "A8"), _chk(B8, FP8, "B8"), _chk(Cacc, F32, "C", (N1, N2))
+    wsn = int(L.lib().vitssl_gemm_fp8_tn_workspace_floats(M, N1, N2))
+    ws = _tn_workspace(A8.device, wsn)
+    ev = _prof_begin()
+    call("vitssl_gemm_fp8_tn", a, b, c, M, N1, N2, _scalar(alpha, "alpha"), _scalar(alpha2, "alpha2"), C.c_void_p(ws.data_ptr()),
+         ws.numel(), _stream())
+    _prof_end(ev, f"gemm_fp8_tn {N1}x{N2}x{M}", 2.0 * M * N1 * N2)
+
+
 def attn_fwd(qkv, out, lse, B, N, H, dh, probs=None, out_fp8=None):
     ev = _prof_begin()
     _attn_fwd(qkv, out, lse, B, N, H, dh, probs, out_fp8)
