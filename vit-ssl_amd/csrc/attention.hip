@@ -147,6 +147,13 @@ __device__ __forceinline__ u32x4 lane_rows_transpose4(const unsigned (&d)[4]) {
   auto f = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
   return u32x4{e[0], e[1], f[0], f[1]};
 }
+__device__ __forceinline__ void store_row_pair16_if(bool ok, bf16_t* row, int p, int g, const u32x2& w0, const u32x2& w1) {
+  auto lo = __builtin_amdgcn_permlane16_swap(w0[0], w1[0], false, false);
+  auto hi = __builtin_amdgcn_permlane16_swap(w0[1], w1[1], false, false);
+  const int odd = g & 1;
+  const u32x4 v = {lo[0], hi[0], lo[1], hi[1]};
+  if (ok) *(u32x4*)(row + (2 * p + odd) * 16 + 4 * (g - odd)) = v;
+}
 __device__ __forceinline__ u32x2 pack4(const f32x4& o) { return u32x2{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])}; }
 
 // ------------------------------------------------------------------ forward
@@ -699,8 +706,10 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(const bf16_t* _
     const f32x4 acc = acc0 + acc1;
     const int q = qs * 32 + 16 * qt_w + li;
     if (q < N) {
-      const u32x2 w = {pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3])};
-      *(u32x2*)(dqkv + ((long long)b * N + q) * stride + h * DH + dt_w * 16 + 4 * g) = w;
+      if (dqkv) {                                 // fp8 path: the bf16 image is optional (kernel-argument uniform)
+        const u32x2 w = {pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3])};
+        *(u32x2*)(dqkv + ((long long)b * N + q) * stride + h * DH + dt_w * 16 + 4 * g) = w;
+      }
       if (dq8) {
         *(unsigned*)(dq8 + ((long long)b * N + q) * stride + h * DH + dt_w * 16 + 4 * g) =
             pack_fp8x4(acc[0] * qsc, acc[1] * qsc, acc[2] * qsc, acc[3] * qsc);
@@ -777,14 +786,14 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(const bf16_t* _
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
       const int key = wave * 32 + kt * 16 + li;
-      if (key < N) {
+      if (dqkv) {                                 // (wave-uniform; the lane predicate sits inside: the row exchange needs all lanes)
         bf16_t* dkg = dqkv + ((long long)b * N + key) * stride + (long long)H * DH + h * DH;
         bf16_t* dvg = dkg + (long long)H * DH;
         // each tensor's 128-byte row leaves in two back-to-back 16-byte-per-lane stores
 #pragma unroll
-        for (int pr = 0; pr < 2; ++pr) store_row_pair16(dkg, pr, g, pack4(dk[2 * pr][kt]), pack4(dk[2 * pr + 1][kt]));
+        for (int pr = 0; pr < 2; ++pr) store_row_pair16_if(key < N, dkg, pr, g, pack4(dk[2 * pr][kt]), pack4(dk[2 * pr + 1][kt]));
 #pragma unroll
-        for (int pr = 0; pr < 2; ++pr) store_row_pair16(dvg, pr, g, pack4(dv[2 * pr][kt]), pack4(dv[2 * pr + 1][kt]));
+        for (int pr = 0; pr < 2; ++pr) store_row_pair16_if(key < N, dvg, pr, g, pack4(dv[2 * pr][kt]), pack4(dv[2 * pr + 1][kt]));
       }
       if (dq8) {    // wave-uniform.  The row's 64 bytes: a 4x4 transpose over the four lane rows gives every lane 16 contiguous bytes
         unsigned qk[4], qv[4];
@@ -962,7 +971,7 @@ extern "C" int vitssl_attn_bwd(const void* qkv, const void* out, const void* dou
 
 extern "C" int vitssl_attn_bwd_fp8(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, void* dqkv_fp8,
                                    const float* qscale, float* qamax, int B, int N, int H, int dh, void* stream) {
-  VS_CHECK_ARG(qkv && out && dout && lse && dqkv && dqkv_fp8, "attn_bwd_fp8: null pointer");
+  VS_CHECK_ARG(qkv && out && dout && lse && dqkv_fp8, "attn_bwd_fp8: null pointer");   // dqkv (bf16) may be NULL
   if (int rc = check_attn_shape("attn_bwd_fp8", B, N, H, dh)) return rc;
   hipStream_t s = (hipStream_t)stream;
 #define VS_CALL(NS) launch_bwd<NS>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, nullptr, (bf16_t*)dqkv, B, N, H, s, \

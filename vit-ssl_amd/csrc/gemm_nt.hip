@@ -479,9 +479,13 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
       }
       // the row's 128 bytes of every bf16 image leave in back-to-back instructions
       if constexpr (EPI == VITSSL_EPI_BF16 || EPI == VITSSL_EPI_GELU || EPI == VITSSL_EPI_DGELU) {
-        store_bf16_row(rsOut0, i, out_a, IC<(EPI == VITSSL_EPI_GELU && NT_STORE_AUX == 0) ? NT_GPRIME_AUX : BF16_AUX>{});
+        // fp8 path: the bf16 image of a dGELU output is optional once its e4m3 image is written (launch-uniform)
+        if (!(Q8 && EPI == VITSSL_EPI_DGELU) || p.out0)
+          store_bf16_row(rsOut0, i, out_a, IC<(EPI == VITSSL_EPI_GELU && NT_STORE_AUX == 0) ? NT_GPRIME_AUX : BF16_AUX>{});
       }
-      if constexpr (EPI == VITSSL_EPI_GELU) store_bf16_row(rsOut1, i, out_b, IC<BF16_AUX>{});
+      if constexpr (EPI == VITSSL_EPI_GELU) {
+        if (!Q8 || p.out1) store_bf16_row(rsOut1, i, out_b, IC<BF16_AUX>{});   // same for the GELU output
+      }
       if constexpr (Q8EPI) {
         if (q8) {
           if ((p.N & 15) == 0) {
@@ -1313,7 +1317,7 @@ extern "C" void vitssl_debug_nt_stamps(void* buf) { g_nt_stamps = (unsigned long
 
 static int gemm_nt_entry(const vitssl_gemm_t* g, int esz, const vitssl_fp8_gemm_t* q, void* stream) {
   const char* who = esz == 1 ? "gemm_fp8_nt" : "gemm_nt";
-  VS_CHECK_ARG(g && g->A && g->B && g->out0, "%s: null operand", who);
+  VS_CHECK_ARG(g && g->A && g->B && (g->out0 || (esz == 1 && g->epilogue == VITSSL_EPI_DGELU && q && q->out_fp8)), "%s: null operand", who);
   VS_CHECK_ARG(g->M > 0 && g->N > 0 && g->K > 0, "%s: empty problem M=%lld N=%d K=%d", who, (long long)g->M, g->N, g->K);
   VS_CHECK_ARG(g->K % (128 / esz) == 0, "%s: K=%d must be a multiple of %d", who, g->K, 128 / esz);
   VS_CHECK_ARG(g->N % 4 == 0, "%s: N=%d must be a multiple of 4", who, g->N);
@@ -1352,7 +1356,7 @@ static int gemm_nt_entry(const vitssl_gemm_t* g, int esz, const vitssl_fp8_gemm_
     case VITSSL_EPI_BF16: return launch_nt<VITSSL_EPI_BF16>(p, s);
     case VITSSL_EPI_F32: return launch_nt<VITSSL_EPI_F32>(p, s);
     case VITSSL_EPI_GELU:
-      VS_CHECK_ARG(g->out1, "%s: EPI_GELU needs out1", who);
+      VS_CHECK_ARG(g->out1 || p.out2, "%s: EPI_GELU needs out1 (or, with fp8 operands, out_fp8)", who);
       return launch_nt<VITSSL_EPI_GELU>(p, s);
     case VITSSL_EPI_RESID:
       VS_CHECK_ARG(g->aux, "%s: EPI_RESID needs aux (residual)", who);

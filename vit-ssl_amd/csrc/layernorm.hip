@@ -118,8 +118,10 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float* __restr
       const int c4 = lane + 64 * v;
       if (c4 < c4n) {
         const f32x4 o = xv[v] * rs * g[v] + b[v];
-        u32x2 w = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
-        *(u32x2*)(yr + 4 * c4) = w;
+        if (!Q8 || y) {                         // fp8 path: the bf16 image is optional (kernel-argument uniform)
+          u32x2 w = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+          *(u32x2*)(yr + 4 * c4) = w;
+        }
         if constexpr (Q8) *(unsigned*)(y8 + row * cols + 4 * c4) = pack_fp8x4(o[0], o[1], o[2], o[3]);
       }
     }
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(LN_THREADS, ln_bwd_blocks(V, HAS_LN, HAS_CS)) void 
         if (c4 < c4n) dx[v] = *(const f32x4*)(g_res + row * cols + 4 * c4);
       }
     }
-    if (gm) {
+    if (gm || (Q8 && gm8)) {
 #pragma unroll
       for (int v = 0; v < V; ++v) {
         const int c4 = lane + 64 * v;
@@ -273,8 +275,10 @@ __global__ __launch_bounds__(LN_THREADS, ln_bwd_blocks(V, HAS_LN, HAS_CS)) void 
             drop_mult4(dk, (unsigned long long)(row * cols + 4 * c4) >> 2, mult);
             o[0] *= mult[0]; o[1] *= mult[1]; o[2] *= mult[2]; o[3] *= mult[3];
           }
-          u32x2 w = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
-          *(u32x2*)(gm + row * cols + 4 * c4) = w;
+          if (gm) {                              // fp8 path: the bf16 image is optional
+            u32x2 w = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+            *(u32x2*)(gm + row * cols + 4 * c4) = w;
+          }
           if constexpr (Q8) {
             *(unsigned*)(gm8 + row * cols + 4 * c4) = pack_fp8x4(o[0] * qs, o[1] * qs, o[2] * qs, o[3] * qs);
             qmax = fmaxf(qmax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
@@ -378,7 +382,7 @@ extern "C" int vitssl_layernorm_fwd(const float* x, const float* gamma, const fl
 
 extern "C" int vitssl_layernorm_fwd_fp8(const float* x, const float* gamma, const float* beta, void* y_bf16, void* y_fp8,
                                         float* mean, float* rstd, int64_t rows, int cols, float eps, void* stream) {
-  VS_CHECK_ARG(x && gamma && beta && y_bf16 && y_fp8 && mean && rstd, "layernorm_fwd_fp8: null pointer");
+  VS_CHECK_ARG(x && gamma && beta && y_fp8 && mean && rstd, "layernorm_fwd_fp8: null pointer");   // y_bf16 may be NULL
   VS_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 2048, "layernorm_fwd_fp8: cols=%d must be a multiple of 4 and <= 2048", cols);
   const int grid = ln_grid(rows, true);
   hipStream_t s = (hipStream_t)stream;
@@ -410,7 +414,7 @@ extern "C" int vitssl_layernorm_bwd_fp8(const void* dy_bf16, const float* x, con
                                         const float* gamma, const float* g_res, float* g_out, void* gm_bf16, void* gm_fp8,
                                         const float* qscale, float* qamax, float* dgamma, float* dbeta, float* gm_colsum,
                                         vitssl_dropout_t drop, int64_t rows, int cols, void* stream) {
-  VS_CHECK_ARG(dy_bf16 && x && mean && rstd && gamma && g_out && dgamma && dbeta && gm_bf16 && gm_fp8, "layernorm_bwd_fp8: null pointer");
+  VS_CHECK_ARG(dy_bf16 && x && mean && rstd && gamma && g_out && dgamma && dbeta && gm_fp8, "layernorm_bwd_fp8: null pointer");   // gm_bf16 may be NULL
   VS_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 2048, "layernorm_bwd_fp8: cols=%d must be a multiple of 4 and <= 2048", cols);
   return launch_ln_bwd<true, true>(dy_bf16, x, mean, rstd, gamma, g_res, g_out, gm_bf16, dgamma, dbeta, gm_colsum, drop, rows,
                                    cols, (hipStream_t)stream, gm_fp8, qscale, qamax);
@@ -418,7 +422,7 @@ extern "C" int vitssl_layernorm_bwd_fp8(const void* dy_bf16, const float* x, con
 
 extern "C" int vitssl_grad_mask_cast_fp8(const float* g, void* gm_bf16, void* gm_fp8, const float* qscale, float* qamax,
                                          float* gm_colsum, vitssl_dropout_t drop, int64_t rows, int cols, void* stream) {
-  VS_CHECK_ARG(g && gm_bf16 && gm_fp8, "grad_mask_cast_fp8: null pointer");
+  VS_CHECK_ARG(g && gm_fp8, "grad_mask_cast_fp8: null pointer");   // gm_bf16 may be NULL
   VS_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 2048, "grad_mask_cast_fp8: cols=%d must be a multiple of 4 and <= 2048", cols);
   return launch_ln_bwd<false, true>(nullptr, nullptr, nullptr, nullptr, nullptr, g, nullptr, gm_bf16, nullptr, nullptr,
                                     gm_colsum, drop, rows, cols, (hipStream_t)stream, gm_fp8, qscale, qamax);

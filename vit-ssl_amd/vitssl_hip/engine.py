@@ -386,18 +386,18 @@ class EncoderStack:
         cur = x
         for i in range(self.L):
             tag = f"{slot}.{i}." if save else f"{slot}.tmp."
-            h1 = g(tag + "h1", (M, D), BF16, dev)
+            h1 = None if self.fp8 else g(tag + "h1", (M, D), BF16, dev)
             mean1 = g(tag + "mean1", (M,), F32, dev)
             rstd1 = g(tag + "rstd1", (M,), F32, dev)
             qkv = g(tag + "qkv", (M, 3 * D), BF16, dev)
             att = g(tag + "att", (M, D), BF16, dev)
             lse = g(tag + "lse", (B, H, T), F32, dev)
             xmid = g(tag + "xmid", (M, D), F32, dev)
-            h2 = g(tag + "h2", (M, D), BF16, dev)
+            h2 = None if self.fp8 else g(tag + "h2", (M, D), BF16, dev)
             mean2 = g(tag + "mean2", (M,), F32, dev)
             rstd2 = g(tag + "rstd2", (M,), F32, dev)
             u = g(tag + "u", (M, F), BF16, dev)
-            a = g(tag + "a", (M, F), BF16, dev)
+            a = None if self.fp8 else g(tag + "a", (M, F), BF16, dev)
             # block output: a fresh buffer per block when saving (it is the next block's
             # LN input), otherwise ping-pong
             xout = g(f"{slot}.{i}.xout" if save else f"{slot}.tmp.xout{i & 1}", (M, D), F32, dev)
@@ -415,12 +415,12 @@ class EncoderStack:
                 h2_8 = g(tag + "h2_8", (M, D), FP8, dev)
                 a8 = g(tag + "a8", (M, F), FP8, dev)
                 (wq, aq), (wo, ao), (w1, a1), (w2, a2) = (st.w8(self._n(i, k)) for k in ("wqkv", "wo", "w1", "w2"))
-                ops.layernorm_fwd_fp8(*ln1, h1, h1_8, mean1, rstd1)
+                ops.layernorm_fwd_fp8(*ln1, None, h1_8, mean1, rstd1)     # (no bf16 images of h1 / h2 / a: nothing reads them)
                 ops.gemm_fp8_nt(h1_8, wq, qkv, L.EPI_BF16, alpha=aq)
                 ops.attn_fwd(qkv, att, lse, B, T, H, dh, probs=probs if i == self.L - 1 else None, out_fp8=att8)
                 ops.gemm_fp8_nt(att8, wo, xmid, L.EPI_RESID, alpha=ao, aux=cur, drop=self._drop(i, 0, seed, training))
-                ops.layernorm_fwd_fp8(*ln2, h2, h2_8, mean2, rstd2)
-                ops.gemm_fp8_nt(h2_8, w1, u, L.EPI_GELU, alpha=a1, bias=b1, out1=a, out_fp8=a8, drop=self._drop(i, 1, seed, training))
+                ops.layernorm_fwd_fp8(*ln2, None, h2_8, mean2, rstd2)
+                ops.gemm_fp8_nt(h2_8, w1, u, L.EPI_GELU, alpha=a1, bias=b1, out_fp8=a8, drop=self._drop(i, 1, seed, training))
                 ops.gemm_fp8_nt(a8, w2, xout, L.EPI_RESID, alpha=a2, bias=b2, aux=xmid, drop=self._drop(i, 2, seed, training))
             else:
                 ops.layernorm_fwd(*ln1, h1, mean1, rstd1)
@@ -537,9 +537,7 @@ class EncoderStack:
         M = B * T
         dev = g.device
         w = self.ws.get
-        gm, gm8 = w("bwd.gm", (M, D), BF16, dev), w("bwd.gm8", (M, D), FP8, dev)
-        du, du8 = w("bwd.du", (M, F), BF16, dev), w("bwd.du8", (M, F), FP8, dev)
-        dqkv, dq8 = w("bwd.dqkv", (M, 3 * D), BF16, dev), w("bwd.dq8", (M, 3 * D), FP8, dev)
+        gm8, du8, dq8 = w("bwd.gm8", (M, D), FP8, dev), w("bwd.du8", (M, F), FP8, dev), w("bwd.dq8", (M, 3 * D), FP8, dev)
         dh_ = w("bwd.dh", (M, D), BF16, dev)
         delta = w("bwd.delta", (B, H, T), F32, dev)
         gv = st.gview
@@ -548,6 +546,11 @@ class EncoderStack:
         inv = lambda i, t: gs["inv"][i, t:t + 1]    # noqa: E731
         am = lambda i, t: gs["amax"][i, t:t + 1]    # noqa: E731
         jit = not self._gs_valid
+        # bf16 images of the gradient operands exist only in the self-calibrating first backward (settle() re-quantises
+        # from them); afterwards every consumer reads the e4m3 image and the producers skip the bf16 store
+        gm = w("bwd.gm", (M, D), BF16, dev) if jit else None
+        du = w("bwd.du", (M, F), BF16, dev) if jit else None
+        dqkv = w("bwd.dqkv", (M, 3 * D), BF16, dev) if jit else None
 
         def settle(i, t, x, x8):
             """first backward only: the producer has just recorded max|x|; take the scale from it and quantise again"""

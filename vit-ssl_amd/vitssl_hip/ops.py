@@ -84,13 +84,13 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps=1e-5):
 
 
 def layernorm_fwd_fp8(x, gamma, beta, y, y8, mean, rstd, eps=1e-5):
-    """LayerNorm forward that also writes the e4m3 image `y8` of its output (fp8 operand path)."""
+    """LayerNorm forward that writes the e4m3 image `y8` of its output (fp8 operand path); the bf16 image `y` is optional."""
     rows, cols = x.shape
     ev = _prof_begin()
     call("vitssl_layernorm_fwd_fp8", _chk(x, F32, "x"), _chk(gamma, F32, "gamma", (cols,)), _chk(beta, F32, "beta", (cols,)),
-         _chk(y, BF16, "y", (rows, cols)), _chk(y8, FP8, "y8", (rows, cols)), _chk(mean, F32, "mean", (rows,)),
+         _opt(y, BF16, "y", (rows, cols)), _chk(y8, FP8, "y8", (rows, cols)), _chk(mean, F32, "mean", (rows,)),
          _chk(rstd, F32, "rstd", (rows,)), rows, cols, float(eps), _stream())
-    _prof_end(ev, "ln_fwd", 0.0, rows * (7 * cols + 8))
+    _prof_end(ev, "ln_fwd", 0.0, rows * ((7 if y is not None else 5) * cols + 8))
 
 
 def _scalar(t, name):
@@ -114,15 +114,15 @@ def layernorm_bwd_fp8(dy, x, mean, rstd, gamma, g_res, g_out, gm, gm8, scale, am
     ev = _prof_begin()
     call("vitssl_layernorm_bwd_fp8", _chk(dy, BF16, "dy", (rows, cols)), _chk(x, F32, "x"), _chk(mean, F32, "mean", (rows,)),
          _chk(rstd, F32, "rstd", (rows,)), _chk(gamma, F32, "gamma", (cols,)), _opt(g_res, F32, "g_res", (rows, cols)),
-         _chk(g_out, F32, "g_out", (rows, cols)), _chk(gm, BF16, "gm", (rows, cols)), _chk(gm8, FP8, "gm8", (rows, cols)),
+         _chk(g_out, F32, "g_out", (rows, cols)), _opt(gm, BF16, "gm", (rows, cols)), _chk(gm8, FP8, "gm8", (rows, cols)),
          _scalar(scale, "scale"), _scalar(amax, "amax"), _chk(dgamma, F32, "dgamma", (cols,)), _chk(dbeta, F32, "dbeta", (cols,)),
          _opt(gm_colsum, F32, "gm_colsum", (cols,)), drop, rows, cols, _stream())
-    _prof_end(ev, "ln_bwd", 0.0, rows * (cols * (2 + 4 + (4 if g_res is not None else 0) + 4 + 3) + 8))
+    _prof_end(ev, "ln_bwd", 0.0, rows * (cols * (2 + 4 + (4 if g_res is not None else 0) + 4 + (3 if gm is not None else 1)) + 8))
 
 
 def grad_mask_cast_fp8(g, gm, gm8, scale, amax, gm_colsum=None, drop=NO_DROP):
     rows, cols = g.shape
-    call("vitssl_grad_mask_cast_fp8", _chk(g, F32, "g"), _chk(gm, BF16, "gm", (rows, cols)), _chk(gm8, FP8, "gm8", (rows, cols)),
+    call("vitssl_grad_mask_cast_fp8", _chk(g, F32, "g"), _opt(gm, BF16, "gm", (rows, cols)), _chk(gm8, FP8, "gm8", (rows, cols)),
          _scalar(scale, "scale"), _scalar(amax, "amax"), _opt(gm_colsum, F32, "gm_colsum", (cols,)), drop, rows, cols, _stream())
 
 
@@ -203,7 +203,9 @@ def gemm_fp8_nt(A8, B8, out0, epilogue, alpha=None, bias=None, aux=None, out1=No
     g.M, g.N, g.K = M, N, K
     g.epilogue = epilogue
     g.bias = _opt(bias, F32, "bias", (N,))
-    g.out0 = _chk(out0, _OUT0_DTYPE[epilogue], "out0", (M, N))
+    if out0 is None and not (epilogue == L.EPI_DGELU and out_fp8 is not None):
+        raise L.VitsslError("gemm_fp8_nt: out0 may only be omitted for EPI_DGELU with out_fp8")
+    g.out0 = _opt(out0, _OUT0_DTYPE[epilogue], "out0", (M, N))
     if epilogue == L.EPI_RESID:
         g.aux = _chk(aux, F32, "aux(residual)", (M, N))
     elif epilogue == L.EPI_DGELU:
@@ -293,7 +295,7 @@ def attn_bwd(qkv, out, dout, lse, dqkv, delta_ws, B, N, H, dh, dqkv_fp8=None, sc
     ev = _prof_begin()
     if dqkv_fp8 is not None:
         call("vitssl_attn_bwd_fp8", _chk(qkv, BF16, "qkv", (B * N, 3 * H * dh)), _chk(out, BF16, "out", (B * N, H * dh)),
-             _chk(dout, BF16, "dout", (B * N, H * dh)), _chk(lse, F32, "lse", (B, H, N)), _chk(dqkv, BF16, "dqkv", (B * N, 3 * H * dh)),
+             _chk(dout, BF16, "dout", (B * N, H * dh)), _chk(lse, F32, "lse", (B, H, N)), _opt(dqkv, BF16, "dqkv", (B * N, 3 * H * dh)),
              _chk(dqkv_fp8, FP8, "dqkv_fp8", (B * N, 3 * H * dh)), _scalar(scale, "scale"), _scalar(amax, "amax"), B, N, H, dh, _stream())
     else:
         _attn_bwd(qkv, out, dout, lse, dqkv, delta_ws, B, N, H, dh)
