@@ -134,8 +134,8 @@ def main():
     ap.add_argument("--mask-ratio", type=float, default=0.6)
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
-                    help="operand type of the forward and input-gradient Linear GEMMs of the encoder blocks (fp8 = OCP e4m3, BASELINE "
-                         "configs[4]; weight-gradient GEMMs, attention and everything else stay bf16).  The headline metric is bf16.")
+                    help="operand type of the Linear GEMMs of the encoder blocks (fp8 = OCP e4m3, BASELINE configs[4]; attention and "
+                         "everything else stay bf16).  The headline metric is bf16.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path on one GPU)")
@@ -281,7 +281,7 @@ def main():
         ach = fl / (ms * 1e-3) / 1e12
         traffic, traffic_src = (pmc_traffic_per_launch(name) if args.model == "vit_b" and args.batch == 256 and args.dtype == "bf16"
                                 else (None, None))
-        peak_of = lambda k: PEAK_FP8_TFLOPS if k == "gemm_fp8_nt" else PEAK_BF16_TFLOPS  # noqa: E731
+        peak_of = lambda k: PEAK_FP8_TFLOPS if k in ("gemm_fp8_nt", "gemm_fp8_tn") else PEAK_BF16_TFLOPS  # noqa: E731
         roofline = {"kernel": {"gemm_nt": "gemm_nt_pp_kernel", "gemm_tn": "gemm_tn_pp_kernel",
                                "gemm_fp8_nt": "gemm_nt_pp_kernel<.., fp8>"}.get(name, name + "_kernel"),
                     "bound": "mfma", "achieved": round(ach, 1), "peak": peak_of(name),
@@ -300,11 +300,11 @@ def main():
         out = {
             "metric": "images_per_sec", "value": round(imgs_per_s, 2), "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "fp8 e4m3 operands in the forward and input-gradient Linear GEMMs, bf16 elsewhere",
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "fp8 e4m3 operands in the Linear GEMMs of the encoder blocks (forward, dgrad, wgrad), bf16 elsewhere",
             "data": "synthetic",
             "config": {"workload": f"{args.model.replace('_', '-').upper().replace('VIT-', 'ViT-')}/{args.patch} SimMIM {args.img}x{args.img} "
                                    f"mask {args.mask_ratio} dropout {args.dropout} AdamW, batch {args.batch}/GPU"
-                                   + (", fp8 weight path (forward + input gradients)" if args.dtype == "fp8" else ""),
+                                   + (", fp8 weight path (forward, input and weight gradients)" if args.dtype == "fp8" else ""),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}"},
             "per_gpu_images_per_sec": round(imgs_per_s / world, 2),
             "mfma_util": round(step_tflops / PEAK_BF16_TFLOPS, 4),
