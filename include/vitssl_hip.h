@@ -123,12 +123,13 @@ int vitssl_gemm_bf16_nt(const vitssl_gemm_t* g, void* stream);
  * output types as vitssl_gemm_bf16_nt, but A [M,K] and B [N,K] are e4m3 bytes, K % 128 == 0, and the
  * MFMA is v_mfma_f32_16x16x128_f8f6f4 (fp32 accumulate).  Epilogues BF16 / F32 / GELU / RESID / DGELU: the
  * forward products and the input-gradient products dX = dY . W (dY quantised with a per-tensor scale that
- * follows the previous step's max |dY|); the weight-gradient GEMM keeps bf16 operands. */
+ * follows the previous step's max |dY|); the weight gradients have their own entry, vitssl_gemm_fp8_tn. */
 typedef struct {
   const float* alpha;  /* device scalar: acc is multiplied by *alpha before the epilogue (dequantisation scale of the
                           weight operand; vitssl_fp8_quantize_weights writes it), or NULL = 1 */
   const float* alpha2; /* second device scalar multiplied in (1 / scale of a scaled gradient operand), or NULL = 1 */
-  void* out_fp8;       /* EPI_GELU: e4m3 [M,N] image of out1; EPI_DGELU: of out0 (the A operand of the next fp8 GEMM); or NULL */
+  void* out_fp8;       /* EPI_GELU: e4m3 [M,N] image of out1; EPI_DGELU: of out0 (the A operand of the next fp8 GEMM); or NULL.
+                          When it is given, the bf16 image it mirrors (out1 / out0) may be NULL and is then not written */
   const float* out_scale; /* device scalar the values are multiplied by before quantisation into out_fp8, or NULL = 1 */
   float* out_amax;     /* device slot: atomic max of |value| written to out_fp8 (before scaling; caller zeroes), or NULL */
 } vitssl_fp8_gemm_t;
@@ -143,7 +144,8 @@ int vitssl_attn_fwd_fp8(const void* qkv, void* out, void* out_fp8, float* lse, f
 int64_t vitssl_gemm_fp8_tn_workspace_floats(int64_t M, int N1, int N2);
 int vitssl_gemm_fp8_tn(const void* A8, const void* B8, float* C, int64_t M, int N1, int N2, const float* alpha,
                        const float* alpha2, float* workspace, int64_t workspace_floats, void* stream);
-/* vitssl_attn_bwd (one-launch form) that also writes dqkv_fp8 = e4m3(dqkv * *qscale) and records max|dqkv| in *qamax */
+/* vitssl_attn_bwd (one-launch form) that also writes dqkv_fp8 = e4m3(dqkv * *qscale) and records max|dqkv| in *qamax;
+ * dqkv (bf16) may be NULL (not written) */
 int vitssl_attn_bwd_fp8(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, void* dqkv_fp8,
                         const float* qscale, float* qamax, int B, int N, int H, int dh, void* stream);
 /* y_fp8[n] = e4m3(clamp(x, -448, 448)), round to nearest even (activations are quantised at unit scale) */
@@ -151,11 +153,11 @@ int vitssl_quantize_fp8(const void* x_bf16, void* y_fp8, int64_t n, void* stream
 /* y_fp8[n] = e4m3(x * *qscale) (qscale NULL = 1); *qamax = max(*qamax, max|x|) (NULL = not recorded; caller zeroes) */
 int vitssl_quantize_fp8_scaled(const void* x_bf16, void* y_fp8, int64_t n, const float* qscale, float* qamax, void* stream);
 /* LayerNorm forward that also emits the e4m3 image of its output (operand of the next fp8 GEMM);
- * y_bf16 is still written: the weight-gradient GEMM of the backward pass reads it. */
+ * y_bf16 may be NULL (not written): with vitssl_gemm_fp8_tn nothing reads the bf16 image. */
 int vitssl_layernorm_fwd_fp8(const float* x, const float* gamma, const float* beta, void* y_bf16, void* y_fp8,
                              float* mean, float* rstd, int64_t rows, int cols, float eps, void* stream);
 /* vitssl_layernorm_bwd / vitssl_grad_mask_cast that also write gm_fp8 = e4m3(gm * *qscale) and record max|gm| in
- * *qamax: the scaled e4m3 operand of the fp8 input-gradient GEMM that consumes gm (gm_bf16 stays: wgrad reads it) */
+ * *qamax: the scaled e4m3 operand of the fp8 GEMMs that consume gm; gm_bf16 may be NULL (not written) */
 int vitssl_layernorm_bwd_fp8(const void* dy_bf16, const float* x, const float* mean, const float* rstd, const float* gamma,
                              const float* g_res, float* g_out, void* gm_bf16, void* gm_fp8, const float* qscale, float* qamax,
                              float* dgamma, float* dbeta, float* gm_colsum, vitssl_dropout_t drop, int64_t rows, int cols,
