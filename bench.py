@@ -283,7 +283,7 @@ def main():
                                 else (None, None))
         peak_of = lambda k: PEAK_FP8_TFLOPS if k in ("gemm_fp8_nt", "gemm_fp8_tn") else PEAK_BF16_TFLOPS  # noqa: E731
         roofline = {"kernel": {"gemm_nt": "gemm_nt_pp_kernel", "gemm_tn": "gemm_tn_pp_kernel",
-                               "gemm_fp8_nt": "gemm_nt_pp_kernel<.., fp8>"}.get(name, name + "_kernel"),
+                               "gemm_fp8_nt": "gemm_nt_pp_kernel<.., fp8>", "gemm_fp8_tn": "gemm_tn_fp8_kernel"}.get(name, name + "_kernel"),
                     "bound": "mfma", "achieved": round(ach, 1), "peak": peak_of(name),
                     "unit": "TFLOP/s", "frac": round(ach / peak_of(name), 4),
                     "traffic": None if traffic is None else round(traffic), "traffic_unit": "bytes/launch (HBM, PMC)",
