@@ -442,3 +442,41 @@ def test_dino_step_with_fp8_operands():
             engine.set_linear_operands("bf16")
     assert all(l == l and l > 0 for l in losses["fp8"])
     assert abs(losses["fp8"][0] - losses["bf16"][0]) < 5e-2 * abs(losses["bf16"][0])
+
+
+def test_simmim_fp8_with_dropout_matches_oracle(fp8_operands):
+    """Dropout on (p = 0.1, the engine's counter-based masks exported to the oracle) together with e4m3 operands:
+    forward outputs and every gradient, second (delayed-scale) step."""
+    from vit_core import _runtime as R
+    from vit_core.ssl.simmim import SimMIMViT
+    from vit_core.ssl.simmim.masking import draw_mask
+    from vitssl_hip import ops
+    from oracle import vit_oracle as O
+    p, B, D, H, F, L, img, patch = 0.1, 4, 128, 2, 256, 2, 64, 16
+    N = (img // patch) ** 2
+    torch.manual_seed(21)
+    model = SimMIMViT(num_blocks=L, input_shape=(3, img, img), embed_dim=D, patch_size=patch, num_heads=H, mlp_dim=F,
+                      dropout=p, mask_ratio=0.6)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV).train()
+    x = torch.rand(B, 3, img, img, generator=torch.Generator().manual_seed(4))
+    for step in range(2):
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(33)
+        pred, tgt = model(x.to(DEV))
+        loss = torch.nn.functional.l1_loss(pred, tgt)
+        loss.backward()
+    torch.manual_seed(33)
+    mask = draw_mask(B, N, 0.6)
+    seed = R.next_seed()
+    keeps = [[ops.dropout_mask(B * N, cols, ops.make_dropout(p, seed, 3 * i + which), DEV).float().cpu().view(B, N, cols)
+              for which, cols in ((0, D), (1, F), (2, D))] for i in range(L)]
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    pe, te = O.simmim_forward(leaves, x, mask, patch, H, emu="fp8", keeps=keeps, p_drop=round(p * 65536) / 65536,
+                              fp8_gscales=model.runtime().stack.fp8_grad_scales().cpu().tolist())
+    assert torch.equal(tgt.cpu(), te) and rel_l2(pred, pe) < 1e-2
+    wl = O.l1_loss_mean(pe, te)
+    wl.backward()
+    assert abs(float(loss.detach()) - float(wl.detach())) < 1e-2 * float(wl.detach())
+    for k, prm in model.named_parameters():
+        assert rel_l2(prm.grad, leaves[k].grad) < 6e-2, (k, rel_l2(prm.grad, leaves[k].grad))
