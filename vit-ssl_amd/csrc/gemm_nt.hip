@@ -739,8 +739,12 @@ __device__ __forceinline__ i32x8 join_frags(const bf16x8& lo, const bf16x8& hi) 
 
 // (target builtins with immediate operands are kept out of the kernel's lambdas: on the host pass a
 // lambda body is checked eagerly and the kernel would silently lose its stub)
+// cache policy of the operand DMA (buffer aux bits: 1 = sc0, 2 = nt, 16 = sc1); developer experiments only
+#ifndef NT_DMA_AUX
+#define NT_DMA_AUX 0
+#endif
 __device__ __forceinline__ void dma16_to_lds(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, unsigned voffset) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_wave_base), 16, voffset, 0, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_wave_base), 16, voffset, 0, 0, NT_DMA_AUX);
 }
 
 template <int EPI, typename CFG, bool F8 = false>
