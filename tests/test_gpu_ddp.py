@@ -207,7 +207,8 @@ def test_dino_two_ranks_share_one_centre(tmp_path):
     assert all((tmp_path / f"dino_ok{r}").exists() for r in range(world))
 
 
-def test_bench_two_rank_path_reports_its_collectives(tmp_path):
+@pytest.mark.parametrize("model,dtype", [("vit_tiny", "bf16"), ("vit_s", "fp8")])
+def test_bench_two_rank_path_reports_its_collectives(tmp_path, model, dtype):
     """bench.py's N > 1 path, rehearsed with two ranks on one GPU (gloo rendezvous, --share-gpu): the
     JSON line carries the self-diagnosis block (world size as the collective sees it, buckets, exposed
     communication) the first real multi-GPU run will be read by."""
@@ -216,7 +217,7 @@ def test_bench_two_rank_path_reports_its_collectives(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--model", "vit_tiny", "--batch", "8", "--img", "64", "--backend", "gloo", "--share-gpu", "--no-cpu-baseline"]
+           "--model", model, "--dtype", dtype, "--batch", "8", "--img", "64", "--backend", "gloo", "--share-gpu", "--no-cpu-baseline"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
