@@ -317,14 +317,19 @@ __global__ __launch_bounds__(LN_THREADS, ln_bwd_blocks(V, HAS_LN, HAS_CS)) void 
   }
 }
 
-// Blocks of 4 rows, grid-stride.  Backward: every block ends with one atomic per column per
-// accumulated vector, so more blocks cost more (2048: 134 us, 4096: 148, 8192: 225 per launch);
-// parking the partials in a workspace and reducing them in a second launch was measured too
-// (140 us + no change in the step) and dropped.  Forward has no such tail: 4096 blocks give
-// 43.5-43.6 ms per ViT-B step against 43.8 with 2048 (uncapped: 43.7).
-inline int ln_grid(long long rows, bool fwd = false) {
+// Blocks of 4 rows, grid-stride.  Backward: every block ends with one atomic per column per accumulated vector, and
+// the register budget admits 2-4 blocks per CU, so a grid larger than what is resident at once only adds such tails:
+// one block per CU (two for rows of <= 512 columns) is fastest now that the next row is prefetched (MI355X, interleaved
+// A/B against the former cap of 2048: M = 50176, D = 768: 123 -> 110 us, with column sums 126 -> 111; D = 1024,
+// M = 25088: 89 -> 75; D = 384: 79 -> 58; DINO local crops, M = 18944, D = 768: 65 -> 37).  Forward has no such tail:
+// 4096 blocks give 43.5-43.6 ms per ViT-B step against 43.8 with 2048 (uncapped: 43.7).
+#ifndef LN_BWD_GRID_CAP
+#define LN_BWD_GRID_CAP 0     // 0 = the rule above; a positive value forces the cap (developer A/B builds)
+#endif
+inline int ln_grid(long long rows, bool fwd = false, int cols = 1024) {
   long long g = (rows + 3) / 4;
-  const long long cap = fwd ? 4096 : 2048;
+  long long cap = fwd ? 4096 : (long long)vitssl_persistent_cus() * (cols <= 512 ? 2 : 1);
+  if (!fwd && LN_BWD_GRID_CAP > 0) cap = LN_BWD_GRID_CAP;
   if (g > cap) g = cap;
   if (g < 1) g = 1;
   return (int)g;
@@ -337,7 +342,7 @@ int launch_ln_bwd(const void* dy, const float* x, const float* mean, const float
                   const float* qscale = nullptr, float* qamax = nullptr) {
   DropKey dk = make_drop_key(drop);
   const int on = dk.thr != 0;
-  const int grid = ln_grid(rows);
+  const int grid = ln_grid(rows, false, cols);
 #define VS_LNB(V)                                                                                                        \
   do {                                                                                                                   \
     if (gm_colsum)                                                                                                       \
