@@ -328,7 +328,10 @@ __global__ __launch_bounds__(LN_THREADS, ln_bwd_blocks(V, HAS_LN, HAS_CS)) void 
 #endif
 inline int ln_grid(long long rows, bool fwd = false, int cols = 1024) {
   long long g = (rows + 3) / 4;
-  long long cap = fwd ? 4096 : (long long)vitssl_persistent_cus() * (cols <= 512 ? 2 : 1);
+#ifndef LN_FWD_GRID_CAP
+#define LN_FWD_GRID_CAP 4096
+#endif
+  long long cap = fwd ? LN_FWD_GRID_CAP : (long long)vitssl_persistent_cus() * (cols <= 512 ? 2 : 1);
   if (!fwd && LN_BWD_GRID_CAP > 0) cap = LN_BWD_GRID_CAP;
   if (g > cap) g = cap;
   if (g < 1) g = 1;
