@@ -359,7 +359,15 @@ __global__ void colsum_bf16_kernel(const bf16_t* __restrict__ x, float* __restri
   const long long r0 = blockIdx.y * per;
   const long long r1 = r0 + per < rows ? r0 + per : rows;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (long long r = r0; r < r1; ++r) {
+  long long r = r0;
+  for (; r + 8 <= r1; r += 8) {                 // eight independent row loads in flight per thread
+    u32x2 w[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) w[u] = *(const u32x2*)(x + (r + u) * cols + c);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += f32x4{bf_lo(w[u][0]), bf_hi(w[u][0]), bf_lo(w[u][1]), bf_hi(w[u][1])};
+  }
+  for (; r < r1; ++r) {
     const u32x2 w = *(const u32x2*)(x + r * cols + c);
     acc += f32x4{bf_lo(w[0]), bf_hi(w[0]), bf_lo(w[1]), bf_hi(w[1])};
   }
