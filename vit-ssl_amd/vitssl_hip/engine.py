@@ -246,6 +246,11 @@ class GradReducer:
         self.gflat = gflat
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        if self.world > 1:
+            # The persistent GEMM workgroups take a CU's whole register file: the collective library's kernels can only run
+            # beside them on CUs the GEMM grids leave alone.  Eight CUs cost ~0.3 % of a step; the
+            # library reads the variable at its first GEMM launch, which comes after the reducer is built.
+            _os.environ.setdefault("VITSSL_RESERVE_CUS", "8")
         self.bucket_elems = int(bucket_mb * 1024 * 1024 / 4)
         self.pending: List[Tuple[int, int]] = []
         self.pending_elems = 0
