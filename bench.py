@@ -159,6 +159,7 @@ def main():
     from vit_core.ssl.simmim import SimMIMViT
     from vitssl_hip import ops
     from vitssl_hip import engine
+    from vitssl_hip import _lib as _vl
     from vitssl_hip.engine import GradReducer
     from vitssl_hip.optim import FusedAdamW
     engine.set_linear_operands(args.dtype)
@@ -188,7 +189,8 @@ def main():
         dist.all_reduce(ones)                               # what the collective library itself sees
         dp = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "allreduce_of_ones": float(ones),
               "grad_bytes": 4 * store.gflat.numel(), "bucket_mb": reducer.bucket_elems * 4 / 2 ** 20,
-              "reserved_cus": int(os.environ.get("VITSSL_RESERVE_CUS", "0") or 0)}
+              "reserved_cus": int(_vl.lib().vitssl_get_reserved_cus()),      # the library's value in force, not the env
+              "nccl_env": {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "NCCL_ALGO", "NCCL_PROTO")}}
         if float(ones) != world:
             raise SystemExit(f"all_reduce over {world} ranks returned {float(ones)}: the process group is not what torchrun launched")
     opt = FusedAdamW(store, lr=1e-4, weight_decay=1e-3)
@@ -237,6 +239,13 @@ def main():
         without = (time.perf_counter() - t1) / k
         dist.broadcast(store.flat, 0)                       # replicas drifted during the un-reduced steps
         store.mark_dirty()
+        # one more step with every bucket bracketed by events on the communication stream: (bytes, ms after the step began,
+        # ms the all-reduce took) -- buckets that start late or run long are queueing behind the persistent GEMM grids
+        reducer.timing = True
+        model.train_step(x, opt, reducer)
+        dp["buckets"] = reducer.bucket_times()
+        reducer.timing = False
+        sync()
         dp.update(buckets_per_step=nb, reduced_bytes_per_step=nbytes, ms_step_with_allreduce=round(with_comm * 1e3, 3),
                   ms_step_without_allreduce=round(without * 1e3, 3), exposed_comm_ms=round((with_comm - without) * 1e3, 3))
         print(f"[bench rank {rank}] {json.dumps(dp)}", file=sys.stderr, flush=True)

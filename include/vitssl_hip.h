@@ -36,6 +36,17 @@ extern "C" {
 const char* vitssl_last_error(void);
 int vitssl_version(void);
 
+/* ---- CUs left to other kernels (data parallelism; no reference counterpart: the reference is single-device,
+ *      utils/train_utils.py:12-16) -------------------------------------------------------------------------
+ * The forward / input-gradient / weight-gradient GEMMs and the LayerNorm backward run ONE persistent workgroup per
+ * CU that owns the CU's whole register file and 129 of its 160 KiB of LDS, so the collective library's all-reduce
+ * kernels cannot share a CU with them.  vitssl_set_reserved_cus(n) makes every persistent grid launched AFTER the
+ * call leave n CUs unoccupied (clamped to [0, CUs - 8]; process-wide; read on every launch, so the order of
+ * "first forward" and "reducer built" does not matter).  The initial value is VITSSL_RESERVE_CUS (default 0). */
+int vitssl_set_reserved_cus(int n);
+int vitssl_get_reserved_cus(void);          /* returns the count in force (not an error code) */
+int vitssl_debug_last_nt_grid(void);        /* workgroups of the last persistent NT GEMM launch (tests) */
+
 /* ---- dropout stream -------------------------------------------------------
  * Counter-based: keep(e) = bits16(seed, site, e) >= round(p * 65536) for element
  * index e = row * ld + col of the tensor the dropout acts on.  The same triple

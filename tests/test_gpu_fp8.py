@@ -444,6 +444,45 @@ def test_dino_step_with_fp8_operands():
     assert abs(losses["fp8"][0] - losses["bf16"][0]) < 5e-2 * abs(losses["bf16"][0])
 
 
+def test_dino_fp8_gradients_follow_bf16_with_per_slot_scales():
+    """DINO calls the student stack's backward twice per step (local crops, then global crops: different row counts and
+    gradient magnitudes).  The delayed gradient scales are kept per slot, so the SECOND step (delayed scales in force for
+    both passes) still gives the bf16 path's parameter gradients within the e4m3 operand band; weights are frozen
+    (lr = 0) so both modes differentiate the same function."""
+    from vit_core.ssl.dino import DINOViT
+    from vit_core.ssl.dino.loss import DINOLoss
+    from vitssl_hip import engine
+    from vitssl_hip.optim import FusedAdamW
+    grads, scales = {}, {}
+    for mode in ("bf16", "fp8"):
+        engine.set_linear_operands(mode)
+        try:
+            torch.manual_seed(0)
+            model = DINOViT(num_blocks=2, input_shape=(3, 64, 64), embed_dim=128, patch_size=16, num_heads=2, mlp_dim=256,
+                            dropout=0.0, output_dim=512, center_momentum=0.9).to(DEV).train()
+            g = torch.Generator().manual_seed(3)
+            # the local crops carry a 16x larger input scale: their gradients differ from the global ones by far more than 2x
+            views = [torch.rand(4, 3, 64, 64, generator=g).to(DEV) for _ in range(2)] + \
+                    [(16.0 * torch.rand(4, 3, 32, 32, generator=g)).to(DEV) for _ in range(3)]
+            crit = DINOLoss(0.04, 0.1)
+            st = model.trainable_store()
+            opt = FusedAdamW(st, lr=0.0, weight_decay=0.0)
+            for _ in range(2):
+                model.train_step(views, 2, crit, opt, None, teacher_momentum=1.0)
+            grads[mode] = {k: st.gview(k).clone() for k in st.names}
+            if mode == "fp8":
+                stack = model.runtime().bb["student"].stack
+                scales = {slot: stack.fp8_grad_scales(slot) for slot in stack._gs_by_slot}
+        finally:
+            engine.set_linear_operands("bf16")
+    assert sorted(scales) == ["g", "l"], list(scales)               # one state per backward pass of the step
+    assert not torch.equal(scales["g"], scales["l"])                # and the two passes did settle on different scales
+    for k, gb in grads["bf16"].items():
+        if float(gb.norm()) == 0.0:
+            continue
+        assert rel_l2(grads["fp8"][k], gb) < 0.12, (k, rel_l2(grads["fp8"][k], gb))
+
+
 def test_simmim_fp8_with_dropout_matches_oracle(fp8_operands):
     """Dropout on (p = 0.1, the engine's counter-based masks exported to the oracle) together with e4m3 operands:
     forward outputs and every gradient, second (delayed-scale) step."""

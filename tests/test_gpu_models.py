@@ -119,6 +119,129 @@ def test_simmim_dropout_matches_oracle_with_exported_masks():
     assert not torch.equal(pred_eval, pred)                                   # dropout differs train vs eval
 
 
+def _export_keeps(p, seed, blocks, rows, D, F, shape):
+    """The engine's three dropout masks per block (drop1, FFN inner, drop2), as float 0/1 tensors for the oracle."""
+    from vitssl_hip import ops
+    return [[ops.dropout_mask(rows, cols, ops.make_dropout(p, seed, 3 * i + which), DEV).float().cpu().view(*shape, cols)
+             for which, cols in ((0, D), (1, F), (2, D))] for i in range(blocks)]
+
+
+@pytest.mark.parametrize("path", ["autograd", "train_step"])
+def test_simmim_dropout_backward_matches_oracle_with_exported_masks(path):
+    """bf16 schedule, dropout ON (the headline bench configuration): every parameter gradient of
+    EncoderStack.backward against the oracle run with the exported masks -- i.e. the SITE wiring of the backward
+    (_drop(i, 0) in the LN2 backward, _drop(i - 1, 2) in the LN1 backward of block i, _drop(last, 2) in grad_mask_cast,
+    g' carrying site 1) is compared with the reference's placement (encoder_block.py:45-46,51-52, feed_forward.py:27).
+    Three blocks, so that first / middle / last block each take their own branch of the schedule."""
+    from vit_core import _runtime as R
+    from vit_core.ssl.simmim import SimMIMViT
+    from vit_core.ssl.simmim.masking import draw_mask
+    from vitssl_hip.optim import FusedAdamW
+    p, B, D, H, F, blocks, img, patch = 0.1, 4, 128, 2, 256, 3, 64, 16
+    N = (img // patch) ** 2
+    torch.manual_seed(5)
+    model = SimMIMViT(num_blocks=blocks, input_shape=(3, img, img), embed_dim=D, patch_size=patch, num_heads=H, mlp_dim=F,
+                      dropout=p, mask_ratio=0.6)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV).train()
+    x = torch.rand(B, 3, img, img, generator=torch.Generator().manual_seed(6))
+    torch.manual_seed(91)
+    mask = draw_mask(B, N, 0.6)
+    if path == "autograd":
+        torch.manual_seed(91)
+        pred, tgt = model(x.to(DEV))
+        loss = torch.nn.functional.l1_loss(pred, tgt)
+        loss.backward()
+        grads = {k: prm.grad for k, prm in model.named_parameters()}
+        torch.manual_seed(91)
+        draw_mask(B, N, 0.6)
+        seed = R.next_seed()
+    else:
+        opt = FusedAdamW(model.flat_store(), lr=1e-4, weight_decay=0.0)
+        torch.manual_seed(92)
+        loss = model.train_step(x.to(DEV), opt, mask_cpu=mask)
+        st = model.flat_store()
+        grads = {k: st.gview(k).view(sd[k].shape) for k in st.names}
+        pred, tgt = model.last_pred, model.last_targets
+        torch.manual_seed(92)
+        seed = R.next_seed()
+    keeps = _export_keeps(p, seed, blocks, B * N, D, F, (B, N))
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    pe, te = O.simmim_forward(leaves, x, mask, patch, H, emu="bf16", keeps=keeps, p_drop=round(p * 65536) / 65536)
+    assert torch.equal(tgt.cpu(), te) and rel_l2(pred, pe) < 1e-2
+    wl = O.l1_loss_mean(pe, te)
+    wl.backward()
+    assert abs(float(loss) - float(wl.detach())) < 1e-2 * float(wl.detach())
+    for k in leaves:
+        assert rel_l2(grads[k], leaves[k].grad) < 5e-2, (path, k, rel_l2(grads[k], leaves[k].grad))
+
+
+def test_encoder_block_dropout_backward_matches_oracle_with_exported_masks():
+    """Stand-alone EncoderBlock, p = 0.25: output, input gradient and every parameter gradient with the masks exported."""
+    from vit_core import EncoderBlock
+    from vit_core import _runtime as R
+    p, B, T, D, H, F = 0.25, 3, 20, 128, 4, 256
+    torch.manual_seed(8)
+    blk = EncoderBlock(D, H, F, p)
+    sd = {k: v.detach().clone() for k, v in blk.state_dict().items()}
+    blk = blk.to(DEV).train()
+    x = torch.randn(B, T, D, generator=torch.Generator().manual_seed(9))
+    w = torch.randn(B, T, D, generator=torch.Generator().manual_seed(10))
+    xg = x.to(DEV).requires_grad_(True)
+    torch.manual_seed(55)
+    y, _ = blk(xg)
+    (y * w.to(DEV)).sum().backward()
+    torch.manual_seed(55)
+    seed = R.next_seed()
+    keep = _export_keeps(p, seed, 1, B * T, D, F, (B, T))[0]
+    for k in keep:
+        assert abs(float(k.mean()) - 0.75) < 0.03
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xo = x.clone().requires_grad_(True)
+    ye, _ = O.encoder_block(xo, leaves, "", H, emu="bf16", keep=keep, p_drop=round(p * 65536) / 65536)
+    assert rel_l2(y, ye) < 1e-2
+    (ye * w).sum().backward()
+    assert rel_l2(xg.grad, xo.grad) < 5e-2, rel_l2(xg.grad, xo.grad)
+    for k, prm in blk.named_parameters():
+        assert rel_l2(prm.grad, leaves[k].grad) < 5e-2, (k, rel_l2(prm.grad, leaves[k].grad))
+
+
+@pytest.mark.parametrize("which", [0, 2])
+def test_dropout_backward_check_detects_a_swapped_site(which):
+    """Negative control of the test above: with ONE dropout site of the backward schedule pointed at another block's
+    stream (what a swapped index in engine.EncoderStack.backward would do) the gradient comparison must fail."""
+    from vit_core import _runtime as R
+    from vit_core.ssl.simmim import SimMIMViT
+    from vit_core.ssl.simmim.masking import draw_mask
+    p, B, D, H, F, blocks, img, patch = 0.1, 4, 128, 2, 256, 3, 64, 16
+    N = (img // patch) ** 2
+    torch.manual_seed(5)
+    model = SimMIMViT(num_blocks=blocks, input_shape=(3, img, img), embed_dim=D, patch_size=patch, num_heads=H, mlp_dim=F,
+                      dropout=p, mask_ratio=0.6)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV).train()
+    x = torch.rand(B, 3, img, img, generator=torch.Generator().manual_seed(6))
+    torch.manual_seed(91)
+    mask = draw_mask(B, N, 0.6)
+    torch.manual_seed(91)
+    pred, tgt = model(x.to(DEV))
+    stack = model.runtime().stack
+    orig = stack._drop
+    stack._drop = lambda i, w, seed, training: orig((i + 1) % blocks if (w == which and i == 1) else i, w, seed, training)
+    try:
+        torch.nn.functional.l1_loss(pred, tgt).backward()
+    finally:
+        stack._drop = orig
+    torch.manual_seed(91)
+    draw_mask(B, N, 0.6)
+    keeps = _export_keeps(p, R.next_seed(), blocks, B * N, D, F, (B, N))
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    pe, te = O.simmim_forward(leaves, x, mask, patch, H, emu="bf16", keeps=keeps, p_drop=round(p * 65536) / 65536)
+    O.l1_loss_mean(pe, te).backward()
+    worst = max(rel_l2(prm.grad, leaves[k].grad) for k, prm in model.named_parameters())
+    assert worst > 5e-2, worst
+
+
 def test_vit_supervised_matches_reference_golden():
     from vit_core import ViT
     g = load_golden("vit_tiny")

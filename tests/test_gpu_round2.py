@@ -213,18 +213,28 @@ def test_reference_checkpoint_roundtrip_on_gpu():
         assert max_abs(sim.state_dict()[k], v) < 2e-6, (k, max_abs(sim.state_dict()[k], v))
 
 
-def test_wrong_device_index_is_refused():
+def test_wrong_device_index_is_refused(monkeypatch):
+    """A tensor of another GPU than the current one must never reach a kernel (launches go to the CURRENT device's
+    stream).  With two visible GPUs the real situation is built; on a one-GPU box the process's current device is
+    made to read as cuda:1 while the tensors live on cuda:0 -- the guard in ops._chk sees exactly the mismatch it
+    exists for, and no launch happens."""
     from vitssl_hip import ops, VitsslError
-    if torch.cuda.device_count() < 2:
-        # one visible GPU: emulate by checking the guard's comparison directly
-        x = torch.zeros(4, 4, device=DEV)
-        assert x.device.index == torch.cuda.current_device()
+    if torch.cuda.device_count() >= 2:
+        with torch.cuda.device(0):
+            x = torch.zeros(64, 64, device="cuda:1")
+            y = torch.empty(64, 64, dtype=torch.bfloat16, device="cuda:1")
+            with pytest.raises(VitsslError, match="current device"):
+                ops.cast_bf16(x, y)
         return
-    with torch.cuda.device(0):
-        x = torch.zeros(64, 64, device="cuda:1")
-        y = torch.empty(64, 64, dtype=torch.bfloat16, device="cuda:1")
-        with pytest.raises(VitsslError, match="current device"):
-            ops.cast_bf16(x, y)
+    x = torch.ones(64, 64, device=DEV)
+    y = torch.full((64, 64), 7.0, dtype=torch.bfloat16, device=DEV)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 1)
+    with pytest.raises(VitsslError, match="current device is cuda:1"):
+        ops.cast_bf16(x, y)
+    monkeypatch.undo()
+    assert float(y.float().min()) == 7.0          # nothing was launched
+    ops.cast_bf16(x, y)                           # and the same call goes through once the devices agree
+    assert float(y.float().max()) == 1.0
 
 
 def test_reserved_cus_knob_keeps_results():

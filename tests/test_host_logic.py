@@ -265,3 +265,128 @@ def test_checkpoint_written_here_loads_into_the_reference(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     total = float(sum(p.double().sum() for p in sim.parameters()))
     assert abs(float(r.stdout.split()[1]) - total) < 1e-9 * max(1.0, abs(total))
+
+
+def test_weight_cache_is_hit_until_a_parameter_changes(monkeypatch):
+    """FlatStore.refresh_weights(): two calls with no parameter change in between launch ONE cast pass; an in-place
+    update through a Parameter, a load_state_dict or mark_dirty() (raw-pointer writers: HIP AdamW / EMA) triggers the
+    next one.  (Round-2 advisor finding: the cache key was overwritten by a loop variable, so every forward re-cast.)"""
+    from vitssl_hip import engine, ops
+    runs = []
+
+    class FakePlan:
+        def run(self, jobs):
+            runs.append(len(jobs))
+
+    monkeypatch.setattr(ops, "CastPlan", FakePlan)
+    lin = torch.nn.Sequential(torch.nn.Linear(64, 128), torch.nn.Linear(128, 64))
+    st = engine.FlatStore(lin, torch.device("cpu"))
+    st.register_weight("w0", lambda: st.view("0.weight", (128, 64)))
+    st.register_weight("w1", lambda: st.view("1.weight", (64, 128)), transposed_too=False)
+    st.refresh_weights()
+    st.refresh_weights()
+    assert runs == [2]
+    assert st.w("w0").shape == (128, 64) and st.w("w0.T").shape == (64, 128) and st.w("w1").shape == (64, 128)
+    with torch.no_grad():
+        lin[0].weight.mul_(0.5)
+    st.refresh_weights()
+    st.refresh_weights()
+    assert runs == [2, 2]
+    st.mark_dirty()
+    st.refresh_weights()
+    assert runs == [2, 2, 2]
+    lin.load_state_dict({k: v.clone() for k, v in lin.state_dict().items()})
+    st.refresh_weights()
+    st.refresh_weights()
+    assert runs == [2, 2, 2, 2]
+    torch.optim.SGD(lin.parameters(), lr=0.1)   # building an optimizer touches nothing
+    st.refresh_weights()
+    assert runs == [2, 2, 2, 2]
+
+
+_DINO_TRANSFORMS = {"transforms": {
+    "globals": [{"name": "RandomResizedCrop", "params": {"size": 224, "scale": [0.5, 1.0]}},
+                {"name": "RandomHorizontalFlip", "params": {"p": 0.5}},
+                {"name": "ColorJitter", "params": {"brightness": 0.4, "contrast": 0.4, "saturation": 0.2, "hue": 0.1}},
+                {"name": "GaussianBlur", "params": {"kernel_size": 7, "sigma": [0.1, 2.0]}},
+                {"name": "ToTensor"}],
+    "train": [{"name": "Resize", "params": {"size": 96}}, {"name": "ToTensor", "params": None}]}}
+
+
+def test_get_transforms_returns_reference_style_callables(monkeypatch):
+    """utils.train_utils.get_transforms keeps the reference's contract (utils/train_utils.py:54-68: one
+    torchvision Compose per list, built with getattr(T, name)(**params)) -- the un-mirrored reference datasets call
+    `self.transform(image)` / `self.transforms["globals"](image)` (data/datasets.py) -- and each callable also carries
+    the GPU multi-crop recipe.  torchvision is not installed in the build image: a stand-in module records the calls."""
+    import sys
+    import types
+    built = []
+
+    class _Op:
+        def __init__(self, **kw):
+            self.kw = kw
+            built.append((type(self).__name__, kw))
+
+        def __call__(self, img):
+            return img + [type(self).__name__]
+
+    class Compose:
+        def __init__(self, ops):
+            self.transforms = ops
+
+        def __call__(self, img):
+            for op in self.transforms:
+                img = op(img)
+            return img
+
+    T = types.ModuleType("torchvision.transforms")
+    T.Compose = Compose
+    for name in ("RandomResizedCrop", "RandomHorizontalFlip", "ColorJitter", "GaussianBlur", "ToTensor", "Resize"):
+        setattr(T, name, type(name, (_Op,), {}))
+    tv = types.ModuleType("torchvision")
+    tv.transforms = T
+    monkeypatch.setitem(sys.modules, "torchvision", tv)
+    monkeypatch.setitem(sys.modules, "torchvision.transforms", T)
+    from utils.train_utils import get_transforms
+    tf = get_transforms(_DINO_TRANSFORMS)
+    assert set(tf) == {"globals", "train"}
+    assert tf["train"]([]) == ["Resize", "ToTensor"]                      # what a reference dataset does per image
+    assert tf["globals"]([])[0] == "RandomResizedCrop" and len(tf["globals"]([])) == 5
+    assert ("Resize", {"size": 96}) in built and ("ToTensor", {}) in built
+    assert ("ColorJitter", {"brightness": 0.4, "contrast": 0.4, "saturation": 0.2, "hue": 0.1}) in built
+    spec = tf["globals"].view_spec                                          # the GPU route's recipe rides along
+    assert spec.size == 224 and tuple(spec.scale) == (0.5, 1.0) and spec.blur_kernel == 7
+    assert tf["train"].view_spec is None                                    # not a multi-crop recipe
+
+
+def test_get_transforms_without_torchvision_names_the_gpu_route(monkeypatch):
+    import sys
+    from utils.train_utils import get_transforms
+    from vitssl_hip import VitsslError
+    monkeypatch.setitem(sys.modules, "torchvision", None)                  # import torchvision -> ImportError
+    tf = get_transforms(_DINO_TRANSFORMS)
+    assert tf["globals"].view_spec.size == 224
+    with pytest.raises(VitsslError, match="INTEGRATION.md section 4"):
+        tf["globals"](object())
+    with pytest.raises(VitsslError, match="torchvision is not installed"):
+        tf["train"](object())
+
+
+def test_setup_device_binds_local_rank(monkeypatch):
+    """One process per GPU: setup_device() binds cuda:LOCAL_RANK (the reference returns bare "cuda",
+    utils/train_utils.py:12-16, which would put every rank on GPU 0)."""
+    from utils import train_utils
+    bound = []
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda i: bound.append(i))
+    monkeypatch.setenv("LOCAL_RANK", "5")
+    assert train_utils.setup_device() == torch.device("cuda:5") and bound == [5]
+    monkeypatch.delenv("LOCAL_RANK")
+    assert train_utils.setup_device() == torch.device("cuda:0") and bound == [5, 0]
+    monkeypatch.setenv("LOCAL_RANK", "9")
+    with pytest.raises(RuntimeError, match="LOCAL_RANK=9"):
+        train_utils.setup_device()
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
+    with pytest.raises(RuntimeError, match="no GPU visible"):
+        train_utils.setup_device()

@@ -32,6 +32,7 @@
 // peeling the under-filled last round into a SMALL-tile launch.
 #include <stdlib.h>
 #include <type_traits>
+#include <atomic>
 #include "common.h"
 
 // cache policy of the epilogue stores (buffer aux bits: 1 = sc0, 2 = nt, 16 = sc1); developer experiments only
@@ -1061,6 +1062,7 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_nt_pp_kernel(NtParams p)
 }
 
 int cu_count() { return vitssl_persistent_cus(); }
+void nt_note_grid(int grid);   // remembers the workgroup count of the last ping-pong launch (vitssl_debug_last_nt_grid)
 
 // 1 (default): 8-wave BK = 64 tiles run the ping-pong kernel; 0: the two-phase loop (VITSSL_NT_PP, developer knob)
 int nt_pp_enabled() {
@@ -1099,6 +1101,7 @@ int launch_pp(NtParams p, hipStream_t s) {
                        : EPI == VITSSL_EPI_RESID ? 8.f : 4.f;
   const float tile_us = (float)(p.K * p.esz / 128) * 1.45f * (float)CFG::MI / 8.f + epi_us;
   p.stagger = (int)(stagger_scale * tile_us * 100.f);
+  nt_note_grid((int)grid);
   hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, CFG, F8>), dim3((unsigned)grid), dim3(CFG::THREADS), LDS, s, p);
   VS_CHECK_LAUNCH("gemm_nt_pp");
   return VITSSL_OK;
@@ -1280,7 +1283,7 @@ int launch_nt(const NtParams& p, hipStream_t s) {
       const long long ea = (long long)p.K * p.esz;
       b.A = (const bf16_t*)((const char*)p.A + brows * ea);
       const int e0 = (EPI == VITSSL_EPI_F32 || EPI == VITSSL_EPI_RESID) ? 4 : 2;
-      b.out0 = (char*)p.out0 + brows * (long long)p.N * e0;
+      if (p.out0) b.out0 = (char*)p.out0 + brows * (long long)p.N * e0;   // (fp8 dGELU after calibration: no bf16 image)
       if (p.out1) b.out1 = (char*)p.out1 + brows * (long long)p.N * 2;
       if (p.out2) b.out2 = (char*)p.out2 + brows * (long long)p.N;
       if (p.aux) b.aux = (const char*)p.aux + brows * (long long)p.N * (EPI == VITSSL_EPI_RESID ? 4 : 2);
@@ -1298,20 +1301,56 @@ int launch_nt(const NtParams& p, hipStream_t s) {
 
 }  // namespace
 
-int vitssl_persistent_cus(void) {
-  static int n = 0;
-  if (!n) {
-    int dev = 0, cus = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    if (cus <= 0) cus = 256;
-    const char* e = getenv("VITSSL_RESERVE_CUS");
-    int reserve = e ? atoi(e) : 0;
-    if (reserve < 0) reserve = 0;
-    if (reserve > cus - 8) reserve = cus - 8;
-    n = cus - reserve;
-  }
+// ---- CUs the persistent grids may occupy --------------------------------------------------------------
+// Explicit library state (round 2 read an environment variable ONCE, at the first GEMM launch, so a reducer built after any
+// forward was silently ignored): vitssl_set_reserved_cus() takes effect at the next launch of every persistent grid (forward /
+// input-gradient / weight-gradient GEMMs, LayerNorm backward).  VITSSL_RESERVE_CUS only provides the initial value.
+static std::atomic<int> g_reserved_cus{-1};     // -1 = not initialised
+static std::atomic<int> g_device_cus{0};
+static std::atomic<int> g_last_nt_grid{0};
+
+static int device_cus() {
+  int c = g_device_cus.load(std::memory_order_relaxed);
+  if (c > 0) return c;
+  int dev = 0, cus = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+  if (cus <= 0) cus = 256;
+  g_device_cus.store(cus, std::memory_order_relaxed);
+  return cus;
+}
+
+static int clamp_reserve(int n) {
+  const int cus = device_cus();
+  if (n < 0) n = 0;
+  if (n > cus - 8) n = cus - 8;
   return n;
+}
+
+extern "C" int vitssl_get_reserved_cus(void) {
+  int r = g_reserved_cus.load(std::memory_order_relaxed);
+  if (r < 0) {
+    const char* e = getenv("VITSSL_RESERVE_CUS");
+    r = clamp_reserve(e ? atoi(e) : 0);
+    g_reserved_cus.store(r, std::memory_order_relaxed);
+  }
+  return r;
+}
+
+extern "C" int vitssl_set_reserved_cus(int n) {
+  if (n < 0) {
+    vitssl_set_error("set_reserved_cus: negative count %d", n);
+    return VITSSL_ERR_ARG;
+  }
+  g_reserved_cus.store(clamp_reserve(n), std::memory_order_relaxed);
+  return VITSSL_OK;
+}
+
+int vitssl_persistent_cus(void) { return device_cus() - vitssl_get_reserved_cus(); }
+
+extern "C" int vitssl_debug_last_nt_grid(void) { return g_last_nt_grid.load(std::memory_order_relaxed); }
+namespace {
+void nt_note_grid(int grid) { g_last_nt_grid.store(grid, std::memory_order_relaxed); }
 }
 
 #ifdef VITSSL_NT_STAMPS

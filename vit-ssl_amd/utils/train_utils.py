@@ -5,10 +5,11 @@ Same entry points and config keys as the reference (utils/train_utils.py:12-51:
 `optimizer`, `lr_scheduler.{main,warmup}`, `warmup_*`), different machinery: every section is
 read through `_spec` into a (name, kwargs) pair, and an AdamW request over a model that exposes
 its flat parameter store is answered with the fused flat-buffer optimizer kernel instead of
-torch.optim.AdamW.  Transform construction (`get_transforms`) is the data side: see
-`data.ViewSpec.from_config` for the DINO view recipes.
+torch.optim.AdamW.  `get_transforms` returns callables with the reference's per-image semantics that also carry the
+GPU multi-crop recipe (`.view_spec`, see `data.ViewSpec.from_config`).
 """
 import logging
+import os
 
 import torch
 from torch import nn, optim
@@ -27,22 +28,70 @@ def _spec(config, *path):
     return cfg_get(node, "name"), dict(cfg_get(node, "params", default={}) or {})
 
 
-def get_transforms(config):
-    """`transforms:` section -> {name: recipe}.  The reference turns every list into a
-    torchvision Compose that runs per image on the CPU (utils/train_utils.py:54-68); here the
-    DINO view lists (`globals`, `locals`: crop, flip, jitter, grayscale, blur, ToTensor) become
-    `data.ViewSpec` recipes that `data.GPUMultiCrop` renders for a whole batch on the GPU.
-    Lists with other transforms are data-loader business outside this package and are rejected
-    by `ViewSpec.from_config`."""
+class _NeedsTorchvision:
+    """Stand-in for one transform list on a host without torchvision: carries the GPU recipe (`view_spec`), and says what
+    is missing when a dataset calls it the way the reference's datasets do (`self.transform(image)`,
+    `self.transforms["globals"](image)`: data/datasets.py:36-38,119-123)."""
+
+    def __init__(self, key, sequence, view_spec):
+        self.key, self.sequence, self.view_spec = key, list(sequence), view_spec
+
+    def __call__(self, image):
+        from vitssl_hip import VitsslError
+        names = ", ".join(str(e["name"]) for e in self.sequence)
+        raise VitsslError(
+            f"transforms[{self.key!r}] ({names}) was called on the CPU, but torchvision is not installed on this host. "
+            "The reference builds these lists from torchvision.transforms (utils/train_utils.py:54-68). Either install "
+            "torchvision, or feed uint8 [B,H,W,3] batches and let data.GPUMultiCrop render the views on the GPU from "
+            "this object's .view_spec (INTEGRATION.md section 4).")
+
+    def __repr__(self):
+        return f"_NeedsTorchvision({self.key!r}, view_spec={self.view_spec})"
+
+
+def _view_spec_or_none(sequence):
+    """The GPU multi-crop recipe of a transform list, or None when the list is not a DINO view recipe."""
     from data import ViewSpec
-    return {name: ViewSpec.from_config(sequence) for name, sequence in dict(cfg_get(config, "transforms") or {}).items()}
+    try:
+        return ViewSpec.from_config(sequence)
+    except (ValueError, KeyError, TypeError):
+        return None
+
+
+def get_transforms(config):
+    """`transforms:` section -> {name: callable}, the reference's contract (utils/train_utils.py:54-68: every list becomes
+    a torchvision Compose built with getattr(T, name)(**params), which the datasets call per image on the CPU).  Each
+    returned callable ALSO carries `.view_spec`: the same list reduced to the numbers `data.GPUMultiCrop` needs to render
+    the DINO views for a whole batch on the GPU (None for lists that are not crop / flip / jitter / gray / blur recipes).
+    Without torchvision the callables refuse to run with a message naming the GPU route."""
+    try:
+        from torchvision import transforms as T
+    except ImportError:
+        T = None
+    out = {}
+    for key, sequence in dict(cfg_get(config, "transforms") or {}).items():
+        sequence = [dict(name=cfg_get(e, "name"), params=dict(cfg_get(e, "params", default={}) or {})) for e in sequence]
+        spec = _view_spec_or_none(sequence)
+        if T is None:
+            out[key] = _NeedsTorchvision(key, sequence, spec)
+            continue
+        pipeline = T.Compose([getattr(T, e["name"])(**e["params"]) for e in sequence])
+        pipeline.view_spec = spec
+        out[key] = pipeline
+    return out
 
 
 def setup_device():
-    """The engine has no CPU path, so unlike the reference this refuses to hand out 'cpu'."""
+    """One process per GPU: binds this process to cuda:LOCAL_RANK (torch.distributed.run exports it; 0 when run alone)
+    and returns that device.  The reference returns bare "cuda" or "cpu" (utils/train_utils.py:12-16); the engine has no
+    CPU path, so unlike the reference this refuses to hand out 'cpu'."""
     if not torch.cuda.is_available():
         raise RuntimeError("no GPU visible: this engine runs the vit_core hot path on MI355X only (no CPU fallback)")
-    device = torch.device("cuda")
+    index = int(os.environ.get("LOCAL_RANK", "0") or 0)
+    if not 0 <= index < torch.cuda.device_count():
+        raise RuntimeError(f"LOCAL_RANK={index} but {torch.cuda.device_count()} GPU(s) are visible")
+    torch.cuda.set_device(index)
+    device = torch.device(f"cuda:{index}")
     logger.info("Using device: %s", device)
     return device
 

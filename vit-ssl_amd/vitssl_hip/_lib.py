@@ -85,6 +85,7 @@ PROTOTYPES = {
     "vitssl_dino_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp],
     "vitssl_colsum_f32": [_vp, _vp, _i64, _i, _vp],
     "vitssl_center_ema": [_vp, _vp, _i, _f, _f, _vp],
+    "vitssl_set_reserved_cus": [_i],
 }
 
 _lib = None
@@ -122,6 +123,9 @@ def lib():
     l.vitssl_gemm_fp8_tn_workspace_floats.argtypes = [C.c_int64, C.c_int, C.c_int]
     l.vitssl_embed_bwd_workspace_floats.restype = C.c_int64
     l.vitssl_embed_bwd_workspace_floats.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+    for getter in ("vitssl_get_reserved_cus", "vitssl_debug_last_nt_grid"):
+        getattr(l, getter).restype = C.c_int
+        getattr(l, getter).argtypes = []
     for name, args in PROTOTYPES.items():
         fn = getattr(l, name)  # AttributeError if the symbol is missing
         fn.restype = C.c_int

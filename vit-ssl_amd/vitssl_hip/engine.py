@@ -184,19 +184,19 @@ class FlatStore:
         if key == self._bf16_key and (self._bf16 or self._fp8):
             return
         jobs = []
-        for key, src, tr, plain in self._cast_jobs:
+        for wname, src, tr, plain in self._cast_jobs:     # (never `key`: that is the cache key stored below)
             w = src()
             R, Cn = w.shape
-            dst = self._bf16.get(key) if plain else None
+            dst = self._bf16.get(wname) if plain else None
             if plain and (dst is None or dst.shape != (R, Cn)):
                 dst = torch.empty(R, Cn, dtype=BF16, device=self.device)
-                self._bf16[key] = dst
+                self._bf16[wname] = dst
             dst_t = None
             if tr:
-                dst_t = self._bf16.get(key + ".T")
+                dst_t = self._bf16.get(wname + ".T")
                 if dst_t is None or dst_t.shape != (Cn, R):
                     dst_t = torch.empty(Cn, R, dtype=BF16, device=self.device)
-                    self._bf16[key + ".T"] = dst_t
+                    self._bf16[wname + ".T"] = dst_t
             jobs.append((w.contiguous(), dst, dst_t))
         if jobs:      # every weight of the store in one launch (was ~50 launches of ~12 us)
             if getattr(self, "_cast_plan", None) is None:
@@ -237,7 +237,8 @@ class GradReducer:
     >= `bucket_elems` and all-reduced (sum) on a side stream.  The 1/world factor is
     folded into the optimizer kernel.  On CPU tensors (gloo, tests) it runs inline."""
 
-    def __init__(self, gflat: torch.Tensor, group=None, bucket_mb: float = 32.0, expect: Optional[Tuple[int, int]] = None):
+    def __init__(self, gflat: torch.Tensor, group=None, bucket_mb: float = 32.0, expect: Optional[Tuple[int, int]] = None,
+                 reserve_cus: int = 8):
         """`expect` = (lo, hi) range of the flat buffer that one backward must hand over exactly once
         (default: the whole buffer); finish() checks it, so a schedule change that forgets or repeats a
         range fails loudly on one GPU instead of silently de-synchronising replicas on eight."""
@@ -246,11 +247,13 @@ class GradReducer:
         self.gflat = gflat
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-        if self.world > 1:
+        if self.world > 1 and gflat.is_cuda:
             # The persistent GEMM workgroups take a CU's whole register file: the collective library's kernels can only run
-            # beside them on CUs the GEMM grids leave alone.  Eight CUs cost ~0.3 % of a step; the
-            # library reads the variable at its first GEMM launch, which comes after the reducer is built.
-            _os.environ.setdefault("VITSSL_RESERVE_CUS", "8")
+            # beside them on CUs the GEMM grids leave alone.  Explicit library state, re-read on
+            # every launch: it does not matter whether a forward ran before this reducer was built.  VITSSL_RESERVE_CUS
+            # (if set) is the user's choice and wins; otherwise `reserve_cus`.
+            if "VITSSL_RESERVE_CUS" not in _os.environ:
+                L.call("vitssl_set_reserved_cus", int(reserve_cus))
         self.bucket_elems = int(bucket_mb * 1024 * 1024 / 4)
         self.pending: List[Tuple[int, int]] = []
         self.pending_elems = 0
@@ -260,6 +263,12 @@ class GradReducer:
         self.launched: List[Tuple[int, int]] = []
         self.expect = expect if expect is not None else (0, gflat.numel())
         self.check_coverage = True
+        # diagnostics (bench.py, first real multi-GPU run): with `timing` on, every bucket is bracketed by events on the
+        # communication stream, and begin() drops one on the compute stream, so bucket_times() can tell whether buckets
+        # queue behind the persistent GEMMs (start late / run long) or finish under the backward
+        self.timing = False
+        self._t0 = None
+        self._bucket_events = []
 
     def _flush(self):
         if not self.pending:
@@ -281,12 +290,30 @@ class GradReducer:
             if self.cuda:
                 self.comm_stream.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(self.comm_stream):
+                    if self.timing:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record(self.comm_stream)
                     self.dist.all_reduce(chunk, group=self.group)
+                    if self.timing:
+                        e1.record(self.comm_stream)
+                        self._bucket_events.append((4 * (hi - lo), e0, e1))
             else:
                 self.handles.append(self.dist.all_reduce(chunk, group=self.group, async_op=True))
 
     def begin(self):
         self.pending, self.pending_elems, self.handles, self.launched = [], 0, [], []
+        if self.timing and self.cuda:
+            self._bucket_events = []
+            self._t0 = torch.cuda.Event(enable_timing=True)
+            self._t0.record(torch.cuda.current_stream())
+
+    def bucket_times(self):
+        """[(bytes, ms from begin() to the bucket's start on the communication stream, ms the all-reduce took)] of the last
+        step run with `timing` on (synchronises)."""
+        if not self._bucket_events:
+            return []
+        torch.cuda.synchronize()
+        return [(nbytes, round(self._t0.elapsed_time(e0), 3), round(e0.elapsed_time(e1), 3)) for nbytes, e0, e1 in self._bucket_events]
 
     def ready(self, lo: int, hi: int):
         self.pending.append((lo, hi))
@@ -362,8 +389,11 @@ class EncoderStack:
         # (0: d(FFN out) -> FC2, 1: d(FFN hidden) -> FC1, 2: d(attention out) -> out-projection, 3: dQKV -> QKV).
         # Delayed scaling: a step quantises with the power-of-two scale derived from the PREVIOUS step's max |value|
         # (one bit of headroom); the very first backward derives each scale from the tensor itself (one extra pass).
-        self._gs = None            # dict of device tensors, allocated on first use
-        self._gs_valid = False
+        # The state is kept PER SLOT: DINO runs the student stack's backward twice per step (local crops, then global
+        # crops: different row counts and gradient magnitudes), and a scale taken from the other pass's maxima would
+        # clamp or lose low bits whenever the two differ by more than the one bit of headroom.
+        self._gs_by_slot: Dict[str, dict] = {}    # slot -> {"scale", "inv", "amax", "used": [L, 4] device tensors, "valid": bool}
+        self._gs = None                           # state of the slot whose backward is running / ran last
 
     # names ----------------------------------------------------------------
     def _n(self, i, leaf):
@@ -458,11 +488,12 @@ class EncoderStack:
         M = B * T
         dev = g.device
         w = self.ws.get
-        gm = w("bwd.gm", (M, D), BF16, dev)
-        du = w("bwd.du", (M, F), BF16, dev)
-        dh_ = w("bwd.dh", (M, D), BF16, dev)
-        dqkv = w("bwd.dqkv", (M, 3 * D), BF16, dev)
-        delta = w("bwd.delta", (B, H, T), F32, dev)
+        bw = f"bwd{M}."     # keyed by the row count: slots of different sizes (DINO local / global crops) keep their own buffers
+        gm = w(bw + "gm", (M, D), BF16, dev)
+        du = w(bw + "du", (M, F), BF16, dev)
+        dh_ = w(bw + "dh", (M, D), BF16, dev)
+        dqkv = w(bw + "dqkv", (M, 3 * D), BF16, dev)
+        delta = w(bw + "delta", (B, H, T), F32, dev)
         gv = st.gview
         last = self.L - 1
         # top of the chain: dropout-mask + cast of g, and the last block's linear_out bias grad
@@ -508,15 +539,18 @@ class EncoderStack:
         # an exact power of two from its exponent field (torch.ldexp multiplies by pow(2, k), which is not exact on the GPU)
         return torch.bitwise_left_shift(k.to(torch.int32) + 127, 23).view(torch.float32)
 
-    def _grad_scale_state(self, dev):
-        if self._gs is None or self._gs["scale"].device != dev:
+    def _grad_scale_state(self, dev, slot: str = "a"):
+        gs = self._gs_by_slot.get(slot)
+        if gs is None or gs["scale"].device != dev:
             mk = lambda v: torch.full((self.L, 4), v, dtype=F32, device=dev)  # noqa: E731
-            self._gs = {"scale": mk(1.0), "inv": mk(1.0), "amax": mk(0.0), "used": mk(1.0)}
-            self._gs_valid = False
-        return self._gs
+            gs = {"scale": mk(1.0), "inv": mk(1.0), "amax": mk(0.0), "used": mk(1.0), "valid": False}
+            self._gs_by_slot[slot] = gs
+        self._gs = gs
+        return gs
 
     def _rescale(self, sel, margin: int):
-        """scale / inv of the selected entries from their recorded max |value| (left alone where that is 0 or not finite)."""
+        """scale / inv of the selected entries of the running slot from their recorded max |value| (left alone where that is 0
+        or not finite)."""
         gs = self._gs
         a = gs["amax"][sel]
         ok = (a > 0) & torch.isfinite(a)
@@ -524,13 +558,16 @@ class EncoderStack:
         gs["scale"][sel] = new
         gs["inv"][sel] = 1.0 / new
 
-    def fp8_grad_scales(self) -> torch.Tensor:
-        """[L, 4] scales the last backward quantised its gradient operands with (tests hand them to the oracle)."""
-        return self._gs["used"].clone()
+    def fp8_grad_scales(self, slot: Optional[str] = None) -> torch.Tensor:
+        """[L, 4] scales the last backward (of `slot`, default: whichever ran last) quantised its gradient operands with
+        (tests hand them to the oracle)."""
+        gs = self._gs if slot is None else self._gs_by_slot[slot]
+        return gs["used"].clone()
 
     def recalibrate_fp8(self):
-        """Derive the gradient scales from the tensors themselves in the next backward (as the first one does)."""
-        self._gs_valid = False
+        """Derive the gradient scales from the tensors themselves in the next backward of every slot (as the first one does)."""
+        for gs in self._gs_by_slot.values():
+            gs["valid"] = False
 
     def _backward_fp8(self, g: torch.Tensor, slot: str, reducer: Optional[GradReducer]) -> torch.Tensor:
         """The schedule of backward() with all eight backward GEMMs of every block on e4m3 operands: the transposed
@@ -542,20 +579,21 @@ class EncoderStack:
         M = B * T
         dev = g.device
         w = self.ws.get
-        gm8, du8, dq8 = w("bwd.gm8", (M, D), FP8, dev), w("bwd.du8", (M, F), FP8, dev), w("bwd.dq8", (M, 3 * D), FP8, dev)
-        dh_ = w("bwd.dh", (M, D), BF16, dev)
-        delta = w("bwd.delta", (B, H, T), F32, dev)
+        bw = f"bwd{M}."     # keyed by the row count: slots of different sizes (DINO local / global crops) keep their own buffers
+        gm8, du8, dq8 = w(bw + "gm8", (M, D), FP8, dev), w(bw + "du8", (M, F), FP8, dev), w(bw + "dq8", (M, 3 * D), FP8, dev)
+        dh_ = w(bw + "dh", (M, D), BF16, dev)
+        delta = w(bw + "delta", (B, H, T), F32, dev)
         gv = st.gview
-        gs = self._grad_scale_state(dev)
+        gs = self._grad_scale_state(dev, slot)
         sc = lambda i, t: gs["scale"][i, t:t + 1]   # noqa: E731
         inv = lambda i, t: gs["inv"][i, t:t + 1]    # noqa: E731
         am = lambda i, t: gs["amax"][i, t:t + 1]    # noqa: E731
-        jit = not self._gs_valid
+        jit = not gs["valid"]
         # bf16 images of the gradient operands exist only in the self-calibrating first backward (settle() re-quantises
         # from them); afterwards every consumer reads the e4m3 image and the producers skip the bf16 store
-        gm = w("bwd.gm", (M, D), BF16, dev) if jit else None
-        du = w("bwd.du", (M, F), BF16, dev) if jit else None
-        dqkv = w("bwd.dqkv", (M, 3 * D), BF16, dev) if jit else None
+        gm = w(bw + "gm", (M, D), BF16, dev) if jit else None
+        du = w(bw + "du", (M, F), BF16, dev) if jit else None
+        dqkv = w(bw + "dqkv", (M, 3 * D), BF16, dev) if jit else None
 
         def settle(i, t, x, x8):
             """first backward only: the producer has just recorded max|x|; take the scale from it and quantise again"""
@@ -605,5 +643,5 @@ class EncoderStack:
         gs["used"].copy_(gs["scale"])
         self._rescale((slice(None), slice(None)), margin=1)
         gs["amax"].zero_()
-        self._gs_valid = True
+        gs["valid"] = True
         return g

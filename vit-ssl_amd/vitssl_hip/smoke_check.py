@@ -1,4 +1,4 @@
-"""One tiny SimMIM train step on the GPU, checked against the CPU oracle (used by
+"""One tiny SimMIM train step (dropout 0.1) on the GPU, checked against the CPU oracle (used by
 __graft_entry__.smoke(); imports oracle/ as the checker only)."""
 import os
 import sys
@@ -15,20 +15,30 @@ def run(device):
     from oracle import vit_oracle as O
     from vit_core.ssl.simmim import SimMIMViT
     from vit_core.ssl.simmim.masking import draw_mask
+    from vit_core import _runtime as R
+    from vitssl_hip import ops
     from vitssl_hip.optim import FusedAdamW
 
     torch.manual_seed(42)
     B, img, P, D, H, F, Lb = 4, 64, 16, 128, 2, 256, 2
     model = SimMIMViT(num_blocks=Lb, input_shape=(3, img, img), embed_dim=D, patch_size=P, num_heads=H, mlp_dim=F,
-                      dropout=0.0, mask_ratio=0.6)
+                      dropout=0.1, mask_ratio=0.6)
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model = model.to(device).train()
     x = torch.rand(B, 3, img, img)
     mask = draw_mask(B, (img // P) ** 2, 0.6)
     opt = FusedAdamW(model.flat_store(), lr=1e-4, weight_decay=1e-3)
+    # dropout ON (the headline configuration): the step draws its dropout seed from torch's CPU generator; the same draw
+    # is repeated here to export the engine's counter-based keep masks and hand them to the oracle
+    torch.manual_seed(43)
     loss = float(model.train_step(x.to(device), opt, mask_cpu=mask))
+    torch.manual_seed(43)
+    seed = R.next_seed()
+    N, p = (img // P) ** 2, 0.1
+    keeps = [[ops.dropout_mask(B * N, cols, ops.make_dropout(p, seed, 3 * i + which), device).float().cpu().view(B, N, cols)
+              for which, cols in ((0, D), (1, F), (2, D))] for i in range(Lb)]
     leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    pred, tgt = O.simmim_forward(leaves, x, mask, P, H)
+    pred, tgt = O.simmim_forward(leaves, x, mask, P, H, keeps=keeps, p_drop=round(p * 65536) / 65536)
     ref = O.l1_loss_mean(pred, tgt)
     ref.backward()
     assert abs(loss - float(ref)) < 1e-2 * float(ref), (loss, float(ref))
