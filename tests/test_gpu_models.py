@@ -180,7 +180,7 @@ def test_encoder_block_dropout_backward_matches_oracle_with_exported_masks():
     """Stand-alone EncoderBlock, p = 0.25: output, input gradient and every parameter gradient with the masks exported."""
     from vit_core import EncoderBlock
     from vit_core import _runtime as R
-    p, B, T, D, H, F = 0.25, 3, 20, 128, 4, 256
+    p, B, T, D, H, F = 0.25, 3, 20, 128, 2, 256
     torch.manual_seed(8)
     blk = EncoderBlock(D, H, F, p)
     sd = {k: v.detach().clone() for k, v in blk.state_dict().items()}

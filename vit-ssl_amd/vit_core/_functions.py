@@ -386,7 +386,7 @@ class _StackFn(Function):
         R.check_saved_generation("encoder stack", ctx.gen, runner.slot_gen.get(ctx.slot, -1))
         st.gflat.zero_()
         g = R.as_f32(dy).reshape(Bn * T, D).clone()
-        g = runner.stack.backward(g, slot=ctx.slot)
+        g = runner.stack.backward(g, slot=ctx.slot, scale_key="run")    # slot names only rotate buffers here
         runner.release_slot(ctx.slot)
         grads = [st.gview(n, p.shape).clone() if p.requires_grad else None for n, p in zip(st.names, st.params)]
         return (None, g.view(Bn, T, D), None, None, None, *grads)

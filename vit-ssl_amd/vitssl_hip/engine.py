@@ -476,12 +476,15 @@ class EncoderStack:
         return cur, probs
 
     # backward ---------------------------------------------------------------
-    def backward(self, g: torch.Tensor, slot: str = "a", reducer: Optional[GradReducer] = None) -> torch.Tensor:
+    def backward(self, g: torch.Tensor, slot: str = "a", reducer: Optional[GradReducer] = None,
+                 scale_key: Optional[str] = None) -> torch.Tensor:
         """g: fp32 [M, D] gradient wrt the stack output (overwritten in place; returned
         holding the gradient wrt the stack input).  Parameter gradients are ACCUMULATED
-        into the store's flat gradient buffer."""
+        into the store's flat gradient buffer.  `scale_key` (fp8 operands only) names the delayed-scaling state this pass
+        uses; default = the slot, i.e. one state per kind of pass (callers that merely rotate slot names over the same kind
+        of pass -- vit_core._functions.StackRunner -- pass one fixed key)."""
         if self.fp8:
-            return self._backward_fp8(g, slot, reducer)
+            return self._backward_fp8(g, slot, reducer, scale_key or slot)
         st, D, H, F, dh = self.store, self.D, self.H, self.F, self.dh
         rec = self._saved[slot]
         B, T, seed, training = rec["B"], rec["T"], rec["seed"], rec["training"]
@@ -569,7 +572,7 @@ class EncoderStack:
         for gs in self._gs_by_slot.values():
             gs["valid"] = False
 
-    def _backward_fp8(self, g: torch.Tensor, slot: str, reducer: Optional[GradReducer]) -> torch.Tensor:
+    def _backward_fp8(self, g: torch.Tensor, slot: str, reducer: Optional[GradReducer], scale_key: str) -> torch.Tensor:
         """The schedule of backward() with all eight backward GEMMs of every block on e4m3 operands: the transposed
         weight images of the store, the activation images saved by the forward, and gradient images written by the
         producers of the gradients (LayerNorm backward, the dGELU epilogue, the attention backward's store phase)."""
@@ -584,7 +587,7 @@ class EncoderStack:
         dh_ = w(bw + "dh", (M, D), BF16, dev)
         delta = w(bw + "delta", (B, H, T), F32, dev)
         gv = st.gview
-        gs = self._grad_scale_state(dev, slot)
+        gs = self._grad_scale_state(dev, scale_key)
         sc = lambda i, t: gs["scale"][i, t:t + 1]   # noqa: E731
         inv = lambda i, t: gs["inv"][i, t:t + 1]    # noqa: E731
         am = lambda i, t: gs["amax"][i, t:t + 1]    # noqa: E731
