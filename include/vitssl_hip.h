@@ -48,10 +48,12 @@ int vitssl_get_reserved_cus(void);          /* returns the count in force (not a
 int vitssl_debug_last_nt_grid(void);        /* workgroups of the last persistent NT GEMM launch (tests) */
 
 /* ---- dropout stream -------------------------------------------------------
- * Counter-based: keep(e) = bits16(seed, site, e) >= round(p * 65536) for element
- * index e = row * ld + col of the tensor the dropout acts on.  The same triple
- * regenerates the mask in backward.  Replaces nn.Dropout at
- * vit_core/encoder_block.py:29-30,45,51 and vit_core/feed_forward.py:16,27. */
+ * Counter-based: keep(e) = [bits16(seed, site, e) >= round(p * 65536)] for element index e = row * cols + col of the
+ * tensor the dropout acts on (rows * cols < 2^34; four consecutive elements share one draw of 64 bits).  The effective
+ * drop probability is round(p * 65536) / 65536 and survivors are scaled by its exact reciprocal.  The same triple
+ * regenerates the mask in backward.  Replaces nn.Dropout at vit_core/encoder_block.py:29-30,45,51 and
+ * vit_core/feed_forward.py:16,27.  The mixer (a 32-bit multiply / xor-shift hash, csrc/common.h) is restated in NumPy
+ * in tests/test_dropout_stream.py, which holds its statistical checks; vitssl_dropout_mask exports the mask. */
 typedef struct {
   float p;        /* drop probability; 0 disables */
   uint32_t site;  /* per (block, site) stream id */

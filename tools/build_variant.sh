@@ -3,7 +3,7 @@
 set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$ROOT/tools/build"; mkdir -p "$OUT/$1"
-CS="$ROOT/vit-ssl_amd/csrc"
+CS="${CSRC_DIR:-$ROOT/vit-ssl_amd/csrc}"   # CSRC_DIR: sources of another commit (git archive <rev> vit-ssl_amd/csrc include | tar -x -C <dir>)
 objs=()
 for f in error.cpp gemm_nt.hip gemm_tn.hip layernorm.hip attention.hip elementwise.hip dino.hip augment.hip fp8.hip; do
   extra=""; [ "$f" = augment.hip ] && extra="-ffp-contract=off"

@@ -68,7 +68,7 @@ KERNEL(k_pkadd, P_DECL, REP32(PKADD), P_SINK)
 #define MAD24(i) asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(a[i]) : "v"(seedu));
 #define BFI(i) asm volatile("v_bfi_b32 %0, %1, %0, %1" : "+v"(a[i]) : "v"(seedu));
 #define PKSUBI16(i) asm volatile("v_pk_sub_i16 %0, %0, %1 clamp" : "+v"(a[i]) : "v"(seedu));
-#define PKASHR(i) asm volatile("v_pk_ashrrev_i16 %0, 15, %0" : "+v"(a[i]));
+#define PKASHR(i) asm volatile("v_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]" : "+v"(a[i]));
 #define PKMAXU16(i) asm volatile("v_pk_max_u16 %0, %0, %1" : "+v"(a[i]) : "v"(seedu));
 #define PERM(i) asm volatile("v_perm_b32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(seedu));
 #define CMPSEL(i) asm volatile("v_cmp_ge_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(seedu) : "vcc");

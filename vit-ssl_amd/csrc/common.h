@@ -84,13 +84,25 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---------------------------------------------------------------- dropout stream
-// Threefry-2x32-style ARX (add / rotate / xor only: all full-rate VALU), 8 rounds,
-// keyed by (seed, site); counter = index of the aligned 4-element group.  One call
-// yields 4 x 16-bit uniforms for elements 4*grp .. 4*grp+3.
+// Counter-based, keyed by (seed, site); counter g = index of the aligned 4-element group, (row * cols + col) >> 2, as
+// 32 bits (callers check rows * cols < 2^34).  One call yields two words = 4 x 16-bit uniforms for elements 4g .. 4g+3
+// (element 0 = low half of a, 1 = high half of a, 2 / 3 = halves of b); an element is KEPT iff its 16 bits, read as a
+// SIGNED number, are >= thr - 32768, i.e. with probability 1 - thr / 65536, thr = round(p * 65536).
+//
+// Round 3: a multiply / xor-shift mixer instead of the 8-round add-rotate-xor network of rounds 1-2.  Measured on MI355X
+// (tools/probes/valu_rates.hip, two waves per SIMD): v_mul_lo_u32 issues every 4.5 cycles, exactly like v_alignbit_b32,
+// so one multiply round (multiply, shift, xor: 9.6 cycles) costs what one ARX round costs and mixes far better; the old
+// network was ~110 cycles per group and, fed with consecutive counters, still showed lag correlations (z ~ 20 over 12 M
+// elements with 8 rounds on a 2-D counter).  This one is ~39 cycles per group; tests/test_dropout_stream.py holds its
+// statistics (keep rate per row / column, 27 lag correlations, chi-square of the 16-bit values, 2-D spectrum, rectangle
+// and within-group products, cross-key correlation) on the NumPy restatement, and the GPU test compares the kernels'
+// masks with that restatement bit for bit.
 struct DropKey {
   unsigned k0, k1;
-  unsigned thr;   // keep iff u16 >= thr ; thr = round(p * 65536)
-  float scale;    // 1 / (1 - p)
+  unsigned thr;        // keep iff u16 (unsigned view) >= thr ... kept for the exported-mask helper and p == 0 tests
+  int thr_s;           // thr - 32768: keep iff (signed 16-bit view) >= thr_s
+  unsigned tm1_pair;   // (thr_s - 1) & 0xffff in both halves: operand of the packed compare
+  float scale;         // 1 / (1 - p_effective)
 };
 
 __host__ __device__ inline DropKey make_drop_key(vitssl_dropout_t d) {
@@ -106,32 +118,54 @@ __host__ __device__ inline DropKey make_drop_key(vitssl_dropout_t d) {
   unsigned t = (unsigned)(p * 65536.0f + 0.5f);
   if (t > 65535u) t = 65535u;
   k.thr = t;
+  k.thr_s = (int)t - 32768;
+  const unsigned tm1 = (unsigned)(k.thr_s - 1) & 0xffffu;     // (never used when t == 0: dropout is off then)
+  k.tm1_pair = tm1 | (tm1 << 16);
   k.scale = t ? 65536.0f / (float)(65536u - t) : 1.0f;
   return k;
 }
 
-__device__ __forceinline__ unsigned rotl32(unsigned x, int r) { return __builtin_rotateleft32(x, r); }
+constexpr unsigned DROP_C0 = 0x9E3779B1u;   // counter multiplier (so that the mixer never sees consecutive integers)
 
-__device__ __forceinline__ u32x2 drop_bits(const DropKey& k, unsigned grp_lo, unsigned grp_hi) {
-  unsigned x0 = grp_lo + k.k0, x1 = grp_hi + k.k1;
-  const unsigned k2 = k.k0 ^ k.k1 ^ 0x1BD11BDAu;
-#define VS_RND(r) x0 += x1; x1 = rotl32(x1, r); x1 ^= x0;
-  VS_RND(13) VS_RND(15) VS_RND(26) VS_RND(6)
-  x0 += k.k1; x1 += k2 + 1u;
-  VS_RND(17) VS_RND(29) VS_RND(16) VS_RND(24)
-  x0 += k2; x1 += k.k0 + 2u;
-#undef VS_RND
-  u32x2 r = {x0, x1};
+// first word of the stream's state for group g: a0 = g * C0 + k0.  Linear in g: kernels that walk rows / columns of a
+// tile form it with one add per group from per-row and per-column terms (drop_a0_row / drop_a0_col).
+__device__ __forceinline__ unsigned drop_a0(const DropKey& k, unsigned g) { return g * DROP_C0 + k.k0; }
+
+__device__ __forceinline__ u32x2 drop_words_a0(const DropKey& k, unsigned a) {
+  a ^= a >> 15;
+  a *= 0x2c1b3c6du;
+  a ^= a >> 12;
+  a *= 0x297a2d39u;
+  a ^= a >> 15;
+  unsigned b = (a ^ k.k1) * 0xc2b2ae35u;
+  b ^= b >> 15;
+  u32x2 r = {a, b};
   return r;
 }
+__device__ __forceinline__ u32x2 drop_words(const DropKey& k, unsigned g) { return drop_words_a0(k, drop_a0(k, g)); }
 
-// keep-multipliers (0 or scale) for the 4 elements of group `grp` (64-bit group index)
-__device__ __forceinline__ void drop_mult4(const DropKey& k, unsigned long long grp, float m[4]) {
-  u32x2 b = drop_bits(k, (unsigned)grp, (unsigned)(grp >> 32));
-  m[0] = ((b[0] & 0xffffu) >= k.thr) ? k.scale : 0.f;
-  m[1] = ((b[0] >> 16) >= k.thr) ? k.scale : 0.f;
-  m[2] = ((b[1] & 0xffffu) >= k.thr) ? k.scale : 0.f;
-  m[3] = ((b[1] >> 16) >= k.thr) ? k.scale : 0.f;
+// 0xffff in every 16-bit half of w whose element is kept (two instructions: saturating packed subtract, packed
+// arithmetic shift): AND it onto a packed bf16 pair.
+__device__ __forceinline__ unsigned drop_keep_pair(const DropKey& k, unsigned w) {
+  unsigned d;
+  asm("v_pk_sub_i16 %0, %1, %2 clamp" : "=v"(d) : "v"(k.tm1_pair), "v"(w));   // sat(thr_s - 1 - u) < 0  <=>  u >= thr_s
+  asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(d) : "v"(d));   // (op_sel_hi: the inline constant's low half shifts BOTH halves)
+  return d;
+}
+// keep decisions of the 4 elements as booleans (fp32 consumers: select, then one fma with the scale)
+__device__ __forceinline__ void drop_keep4(const DropKey& k, const u32x2& w, bool keep[4]) {
+  const int t = (int)((unsigned)k.thr_s << 16);
+  keep[0] = (int)(w[0] << 16) >= t;
+  keep[1] = (int)w[0] >= t;
+  keep[2] = (int)(w[1] << 16) >= t;
+  keep[3] = (int)w[1] >= t;
+}
+// keep-multipliers (0 or scale) for the 4 elements of group g
+__device__ __forceinline__ void drop_mult4(const DropKey& k, unsigned g, float m[4]) {
+  bool keep[4];
+  drop_keep4(k, drop_words(k, g), keep);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) m[r] = keep[r] ? k.scale : 0.f;
 }
 
 // ---------------------------------------------------------------- GELU (exact-erf form)
@@ -165,6 +199,22 @@ __device__ __forceinline__ void gelu_both(float x, float& y, float& dy) {
   const float cdf = 0.5f * (1.0f + erfv);
   y = x * cdf;
   dy = fmaf(x * 0.3989422804014327f, e, cdf);
+}
+// the same with a common factor s folded into the constants: y = s gelu(x), dy = s gelu'(x); hs = 0.5 s, cs = s / sqrt(2 pi)
+// (the GEMM epilogue's dropout scale: no separate multiplies)
+__device__ __forceinline__ void gelu_both_scaled(float x, float hs, float cs, float& y, float& dy) {
+  const float ax = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  poly *= t;
+  const float e = __expf(-ax * ax);                 // = exp(-x^2/2)
+  const float erfv = copysignf(fmaf(-poly, e, 1.0f), x);
+  const float cdf = fmaf(hs, erfv, hs);             // s Phi(x)
+  y = x * cdf;
+  dy = fmaf(x * cs, e, cdf);
 }
 // d/dx gelu(x) = Phi(x) + x * phi(x)
 __device__ __forceinline__ float dgelu_f(float x) {

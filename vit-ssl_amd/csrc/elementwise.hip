@@ -18,7 +18,7 @@ __global__ void dropout_mask_kernel(unsigned char* keep, long long ngroups, Drop
   const long long grp = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (grp >= ngroups) return;
   float m[4];
-  drop_mult4(dk, (unsigned long long)grp, m);
+  drop_mult4(dk, (unsigned)grp, m);
   uchar4 o;
   o.x = m[0] != 0.f; o.y = m[1] != 0.f; o.z = m[2] != 0.f; o.w = m[3] != 0.f;
   if (dk.thr == 0) o = make_uchar4(1, 1, 1, 1);
@@ -386,6 +386,7 @@ inline unsigned stream_grid(long long n4) {
 
 extern "C" int vitssl_dropout_mask(uint8_t* keep, int64_t rows, int64_t cols, vitssl_dropout_t d, void* stream) {
   VS_CHECK_ARG(keep && rows > 0 && cols > 0 && cols % 4 == 0, "dropout_mask: cols must be a multiple of 4");
+  VS_CHECK_ARG((unsigned long long)rows * (unsigned long long)cols < (1ull << 34), "dropout_mask: the stream's group counter is 32 bits (rows * cols < 2^34)");
   const long long ng = rows * cols / 4;
   hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_grid(ng)), dim3(EW_THREADS), 0, (hipStream_t)stream, keep, ng, make_drop_key(d));
   VS_CHECK_LAUNCH("dropout_mask");

@@ -60,6 +60,10 @@
 #ifndef NT_ROWS128
 #define NT_ROWS128 0
 #endif
+// 1 (default): the GELU epilogue of the ping-pong kernel reads gelu / gelu' from an LDS table; 0: arithmetic only (A/B builds)
+#ifndef NT_GELU_LUT
+#define NT_GELU_LUT 1
+#endif
 // diagnostic builds only (tools/build_variant.sh): 1 = epilogue arithmetic and loads but NO stores,
 // 2 = stores but no GELU / dropout arithmetic and no residual / g' loads
 #ifndef NT_ABLATE
@@ -165,11 +169,45 @@ __device__ __forceinline__ void wait_vmcnt() {
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---- GELU by table (EPI_GELU of the ping-pong kernel) ---------------------------------------------------------
+// The epilogue evaluates gelu / gelu' on the pre-activation ROUNDED TO bf16 (the reference's autocast stores that tensor
+// in bf16, feed_forward.py:26-27), i.e. on one of 65536 inputs, and writes two bf16 results.  For 2^-14 <= |u| < 16
+// (18 binades x 128 mantissas x 2 signs = 4608 inputs, all but ~1e-4 of the elements) the pair
+// (bf16(s gelu(u)), bf16(s gelu'(u))), s = dropout scale, is read from an 18 KiB table in the LDS the staging buffers
+// leave free; the workgroup fills it once per launch with gelu_both_scaled, so every entry is bit-identical to what the
+// arithmetic path produces for that input.  A 4-element group with any lane outside the range (wave-uniform test) is
+// redone with the arithmetic.  Why: the arithmetic is ~60 VALU cycles per element of an epilogue that is VALU-issue
+// bound (tools/probes/valu_rates.hip: v_exp / v_rcp 8.2 cycles, packed fp32 4.8 per pair); the lookup is ~25 cycles of
+// index arithmetic plus one ds_read_b32 on the otherwise idle LDS pipe (8 cycles per wave-instruction per CU with random
+// addresses).
+constexpr int GLUT_E_LO = 127 - 14;                       // bf16 exponent field of 2^-14
+constexpr int GLUT_BINADES = 18;                          // ... up to [8, 16)
+constexpr int GLUT_ENTRIES = GLUT_BINADES * 128 * 2;      // (magnitude index, sign)
+constexpr int GLUT_BYTES = GLUT_ENTRIES * 4;
+constexpr unsigned GLUT_LO8 = (unsigned)GLUT_E_LO << 10;  // magnitude part of the byte address: (h & 0x7fff) << 3
+constexpr unsigned GLUT_HI8 = (unsigned)(GLUT_E_LO + GLUT_BINADES) << 10;
+
+// byte address (relative to table base - GLUT_LO8) of the entries of the two bf16 halves of w
+__device__ __forceinline__ void glut_addr2(unsigned w, unsigned& mag0, unsigned& sgn0, unsigned& mag1, unsigned& sgn1) {
+  mag0 = (w << 3) & 0x3fff8u;
+  sgn0 = (w >> 13) & 4u;
+  mag1 = (w >> 13) & 0x3fff8u;
+  sgn1 = (w >> 29) & 4u;
+}
+// plain LDS loads (the compiler counts them): checked in the .s that no vmcnt wait is attached to them -- the operand DMA in
+// flight during the epilogue writes other LDS bytes, but hipcc cannot always prove that (cdna guide, "three .s-level traps")
+template <int OFF>
+__device__ __forceinline__ unsigned glut_read(const char* smem, unsigned a) {
+  return *(const unsigned*)(smem + OFF + a);
+}
+
 // Fused epilogue of one 128x64 wave tile (shared by both main-loop variants).
-template <int EPI, typename CFG, bool Q8 = false>
+template <int EPI, typename CFG, bool Q8 = false, int GLUT_OFF = -1>
 __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][CFG::MI], const long long m0, const int n0,
-                                            const int wm, const int wn, const int lane) {
+                                            const int wm, const int wn, const int lane, const char* lds = nullptr) {
   constexpr int MI = CFG::MI;
+  // GLUT_OFF >= 0: LDS byte offset of the GELU table minus GLUT_LO8 (the ds_read's immediate)
+  constexpr bool GLUT = EPI == VITSSL_EPI_GELU && GLUT_OFF >= 0 && NT_ABLATE == 0 && !Q8;   // (the e4m3 image is quantised from fp32)
   // ------------------------------------------------------------------ epilogue
   // All global traffic of the epilogue goes through raw buffer instructions on a window
   // that starts at the tile's first row: rows past M fall outside num_records and columns
@@ -177,8 +215,10 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
   // branch.  That lets every residual / g' load of a 64-column half be issued back to back
   // before the first use (the branchy form waited for each 16-byte load in turn: 32
   // dependent HBM round trips per wave, measured +65 us on the N = K = 768 projection).
+  // column sums exist for the epilogues that produce a gradient operand (bias gradients); the entry point rejects them elsewhere
+  constexpr bool CS = EPI == VITSSL_EPI_BF16 || EPI == VITSSL_EPI_F32 || EPI == VITSSL_EPI_DGELU;
   float csum[4][4];
-  if (p.colsum) {
+  if (CS && p.colsum) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -304,11 +344,23 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
   int nn[2][2];
   bool okn[2][2];
   f32x4 bias4[2][2];
+  // dropout stream (common.h): the state word of group g = row * N/4 + col/4 is g * C0 + k0 = (row term) + (column term);
+  // the row term advances by a launch constant per 16-row tile, the column terms are four lane constants
+  constexpr bool DROPS = EPI == VITSSL_EPI_GELU || EPI == VITSSL_EPI_RESID;
+  unsigned a0col[2][2];
+  const unsigned a0rowstep = 16u * (unsigned)(p.N >> 2) * DROP_C0;
+  unsigned a0row = 0;
+  if (DROPS && p.drop_on)
+    a0row = drop_a0(p.dk, (unsigned)(m0 + wm * CFG::WROWS + (lane & 15) + p.m_base) * (unsigned)(p.N >> 2));
+  // GELU: the dropout scale is folded into the two constants of gelu_both_scaled
+  const float gelu_hs = (DROPS && p.drop_on) ? 0.5f * p.dk.scale : 0.5f;
+  const float gelu_cs = (DROPS && p.drop_on) ? 0.3989422804014327f * p.dk.scale : 0.3989422804014327f;
 #pragma unroll
   for (int jp = 0; jp < 2; ++jp)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       nn[jp][h] = n0 + wn * 64 + (2 * jp + h) * 16 + 4 * g4;
+      a0col[jp][h] = (unsigned)(nn[jp][h] >> 2) * DROP_C0;
       okn[jp][h] = nn[jp][h] < p.N;
       bias4[jp][h] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (p.bias && (EPI != EPI_F32_SPLITK || blockIdx.y == 0) && okn[jp][h]) bias4[jp][h] = *(const f32x4*)(p.bias + nn[jp][h]);
@@ -387,6 +439,27 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
       const bool okm = m < p.M;
       u32x2 out_a[2][2], out_b[2][2];   // bf16 images of this row, both pairs: stored together below
       unsigned out_q[2][2];             // e4m3 image of out_b (fp8 operand path)
+      // GELU by table: the row's 16 lookups are issued first and fly under the dropout-stream arithmetic below
+      unsigned gl[16];                  // (bf16 s gelu(u)) | (bf16 s gelu'(u)) << 16 per element: [jp][h][r]
+      bool gslow[2][2];                 // wave-uniform: some lane of this group is outside the table's range
+      if constexpr (GLUT) {
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const f32x4 vv = acc[2 * jp + h][i] + bias4[jp][h];
+            const unsigned w0 = pack_bf2(vv[0], vv[1]), w1 = pack_bf2(vv[2], vv[3]);
+            unsigned mg[4], sg[4];
+            glut_addr2(w0, mg[0], sg[0], mg[1], sg[1]);
+            glut_addr2(w1, mg[2], sg[2], mg[3], sg[3]);
+            const unsigned mn = min(min(mg[0], mg[1]), min(mg[2], mg[3])), mx = max(max(mg[0], mg[1]), max(mg[2], mg[3]));
+            gslow[jp][h] = __builtin_amdgcn_ballot_w64(mn < GLUT_LO8 || mx >= GLUT_HI8) != 0;
+            // (a lane above the range is clamped onto the last entry, one below it reads staging bytes: both are discarded)
+            const int q = 8 * jp + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gl[q + r] = glut_read<GLUT_OFF>(lds, min(mg[r], GLUT_HI8 - 8u) | sg[r]);
+          }
+      }
 #pragma unroll
       for (int jp = 0; jp < 2; ++jp) {
         f32x4 v[2] = {acc[2 * jp][i] + bias4[jp][0], acc[2 * jp + 1][i] + bias4[jp][1]};
@@ -397,10 +470,28 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
         } else if constexpr (EPI == VITSSL_EPI_GELU) {
           // u = bf16(acc + bias) (never stored); out1 = a = keep*scale*gelu(u) feeds the next
           // GEMM; out0 = g' = keep*scale*gelu'(u) is what the backward dGELU epilogue needs.
+          // keep masks of each group's two bf16 pairs (0xffff per kept element), ANDed onto the packed outputs
+          unsigned km[2][2] = {{0xffffffffu, 0xffffffffu}, {0xffffffffu, 0xffffffffu}};
+          u32x2 dw[2] = {u32x2{0u, 0u}, u32x2{0u, 0u}};
+          const bool dropping = p.drop_on && NT_ABLATE != 2;
+          if (dropping) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              dw[h] = drop_words_a0(p.dk, a0row + (unsigned)i * a0rowstep + a0col[jp][h]);
+              km[h][0] = drop_keep_pair(p.dk, dw[h][0]);
+              km[h][1] = drop_keep_pair(p.dk, dw[h][1]);
+            }
+          }
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
-            float mult[4] = {1.f, 1.f, 1.f, 1.f};
-            if (p.drop_on && NT_ABLATE != 2) drop_mult4(p.dk, (unsigned long long)((m + p.m_base) * p.N + nn[jp][h]) >> 2, mult);
+            if (GLUT && !gslow[jp][h]) {
+              const int q = 8 * jp + 4 * h;
+              out_b[jp][h] = u32x2{__builtin_amdgcn_perm(gl[q + 1], gl[q], 0x05040100u) & km[h][0],
+                                   __builtin_amdgcn_perm(gl[q + 3], gl[q + 2], 0x05040100u) & km[h][1]};
+              out_a[jp][h] = u32x2{__builtin_amdgcn_perm(gl[q + 1], gl[q], 0x07060302u) & km[h][0],
+                                   __builtin_amdgcn_perm(gl[q + 3], gl[q + 2], 0x07060302u) & km[h][1]};
+              continue;
+            }
             float y[4], d[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -409,13 +500,17 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
                 d[r] = v[h][r] * 0.5f;
                 continue;
               }
-              gelu_both(round_bf(v[h][r]), y[r], d[r]);
-              y[r] *= mult[r];
-              d[r] *= mult[r];
+              gelu_both_scaled(round_bf(v[h][r]), gelu_hs, gelu_cs, y[r], d[r]);
             }
-            out_b[jp][h] = u32x2{pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
-            out_a[jp][h] = u32x2{pack_bf2(d[0], d[1]), pack_bf2(d[2], d[3])};
+            out_b[jp][h] = u32x2{pack_bf2(y[0], y[1]) & km[h][0], pack_bf2(y[2], y[3]) & km[h][1]};
+            out_a[jp][h] = u32x2{pack_bf2(d[0], d[1]) & km[h][0], pack_bf2(d[2], d[3]) & km[h][1]};
             if constexpr (Q8) {
+              if (dropping) {
+                bool keep[4];
+                drop_keep4(p.dk, dw[h], keep);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = keep[r] ? y[r] : 0.f;
+              }
               out_q[jp][h] = pack_fp8x4(y[0] * qs, y[1] * qs, y[2] * qs, y[3] * qs);
               if (okm && okn[jp][h]) qmax = fmaxf(qmax, fmaxf(fmaxf(fabsf(y[0]), fabsf(y[1])), fmaxf(fabsf(y[2]), fabsf(y[3]))));
             }
@@ -450,11 +545,13 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             if (p.drop_on && NT_ABLATE != 2) {
-              float mult[4];
-              drop_mult4(p.dk, (unsigned long long)((m + p.m_base) * p.N + nn[jp][h]) >> 2, mult);
-              v[h][0] *= mult[0]; v[h][1] *= mult[1]; v[h][2] *= mult[2]; v[h][3] *= mult[3];
+              bool keep[4];
+              drop_keep4(p.dk, drop_words_a0(p.dk, a0row + (unsigned)i * a0rowstep + a0col[jp][h]), keep);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[h][r] = fmaf(keep[r] ? v[h][r] : 0.f, p.dk.scale, res[ii][jp][h][r]);
+            } else {
+              v[h] += res[ii][jp][h];
             }
-            v[h] += res[ii][jp][h];
           }
           store_f32_pair(rsOut0, i, jp, v[0], v[1], nn[jp]);
         } else {   // VITSSL_EPI_EMBED (one launch per step: plain addressing)
@@ -469,7 +566,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
             *(f32x4*)((float*)p.out0 + orow * p.N + nn[jp][h]) = v[h];
           }
         }
-        if (p.colsum) {
+        if (CS && p.colsum) {
 #pragma unroll
           for (int h = 0; h < 2; ++h)
             if (okm && okn[jp][h]) {
@@ -511,7 +608,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
     }
   }
 
-  if (p.colsum) {
+  if (CS && p.colsum) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -757,6 +854,11 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_nt_pp_kernel(NtParams p)
   constexpr int BUF = CFG::BUF_BYTES;
   constexpr int DUMMY = 2 * BUF;                       // 1 KiB sink for the slots a short A1 unit does not need
   constexpr unsigned OOBV = 0x80000000u;
+  // EPI_GELU (bf16 operands): the 18 KiB GELU table sits behind the sink (see "GELU by table" above nt_epilogue)
+  constexpr bool USE_GLUT = EPI == VITSSL_EPI_GELU && !F8 && NT_ABLATE == 0 && NT_GELU_LUT;
+  constexpr int GLUT_BASE = 2 * BUF + 1024;
+  constexpr int GLUT_IMM = USE_GLUT ? GLUT_BASE - (int)GLUT_LO8 : -1;
+  static_assert(!USE_GLUT || (GLUT_IMM >= 0 && GLUT_IMM < 65536), "the table's offset must fit the ds_read immediate");
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1008,6 +1110,21 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_nt_pp_kernel(NtParams p)
   stage_b(c1, 1, IC<0>{});
   stage_a(c1, 1, IC<0>{});
   Cur c2 = cur_next(c1);
+  if constexpr (USE_GLUT) {
+    // fill the table while the first K-tiles are in flight: entry (magnitude index, sign) = the two bf16 results for that
+    // bf16 input, from the SAME function the arithmetic path evaluates.  Every wave passes the K loop's barriers before
+    // the first epilogue reads it.
+    const float hs = p.drop_on ? 0.5f * p.dk.scale : 0.5f;
+    const float cs = p.drop_on ? 0.3989422804014327f * p.dk.scale : 0.3989422804014327f;
+    unsigned* tab = (unsigned*)(smem + GLUT_BASE);
+    for (int e = threadIdx.x; e < GLUT_ENTRIES; e += CFG::THREADS) {
+      const unsigned h = (unsigned)((e >> 1) + (GLUT_E_LO << 7)) | ((unsigned)(e & 1) << 15);
+      float y, dy;
+      gelu_both_scaled(bf2f((bf16_t)h), hs, cs, y, dy);
+      tab[e] = (unsigned)f2bf(y) | ((unsigned)f2bf(dy) << 16);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
   wait_vmcnt_exact<8>();                               // B0, A0 of K-tile 0 have landed
   section();
 
@@ -1047,7 +1164,7 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_nt_pp_kernel(NtParams p)
           for (int i = 0; i < MI; ++i) acc[j][i] *= al;
       }
     }
-    nt_epilogue<EPI, CFG, F8>(p, acc, m0, n0, wm, wn, lane);
+    nt_epilogue<EPI, CFG, F8, GLUT_IMM>(p, acc, m0, n0, wm, wn, lane, smem);
     stamp(round, 2);
 #ifdef VITSSL_NT_STAMPS
     if (p.stamps) {                                    // diagnostic: when have this wave's stores been acknowledged?
@@ -1076,7 +1193,7 @@ int nt_pp_enabled() {
 
 template <int EPI, typename CFG, bool F8 = false>
 int launch_pp(NtParams p, hipStream_t s) {
-  constexpr int LDS = 2 * CFG::BUF_BYTES + 1024;
+  constexpr int LDS = 2 * CFG::BUF_BYTES + 1024 + ((EPI == VITSSL_EPI_GELU && !F8 && NT_ABLATE == 0 && NT_GELU_LUT) ? GLUT_BYTES : 0);
   static bool attr_done = false;  // idempotent; a benign race sets the same value
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, CFG, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -1395,6 +1512,10 @@ static int gemm_nt_entry(const vitssl_gemm_t* g, int esz, const vitssl_fp8_gemm_
   p.stamps = g_nt_stamps;
 #endif
   hipStream_t s = (hipStream_t)stream;
+  VS_CHECK_ARG(!g->colsum || g->epilogue == VITSSL_EPI_BF16 || g->epilogue == VITSSL_EPI_F32 || g->epilogue == VITSSL_EPI_DGELU,
+               "%s: column sums are built for the BF16 / F32 / DGELU epilogues only", who);
+  VS_CHECK_ARG(!p.drop_on || (unsigned long long)g->M * (unsigned long long)g->N < (1ull << 34),
+               "%s: dropout over %lld x %d elements: the stream's group counter is 32 bits (M * N < 2^34)", who, (long long)g->M, g->N);
   switch (g->epilogue) {
     case VITSSL_EPI_BF16: return launch_nt<VITSSL_EPI_BF16>(p, s);
     case VITSSL_EPI_F32: return launch_nt<VITSSL_EPI_F32>(p, s);

@@ -271,9 +271,10 @@ __global__ __launch_bounds__(LN_THREADS, ln_bwd_blocks(V, HAS_LN, HAS_CS)) void 
         if (c4 < c4n) {
           f32x4 o = dx[v];
           if (drop_on) {
-            float mult[4];
-            drop_mult4(dk, (unsigned long long)(row * cols + 4 * c4) >> 2, mult);
-            o[0] *= mult[0]; o[1] *= mult[1]; o[2] *= mult[2]; o[3] *= mult[3];
+            bool keep[4];
+            drop_keep4(dk, drop_words(dk, (unsigned)row * (unsigned)c4n + (unsigned)c4), keep);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = keep[r] ? o[r] * dk.scale : 0.f;
           }
           if (gm) {                              // fp8 path: the bf16 image is optional
             u32x2 w = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
@@ -345,6 +346,8 @@ int launch_ln_bwd(const void* dy, const float* x, const float* mean, const float
                   const float* qscale = nullptr, float* qamax = nullptr) {
   DropKey dk = make_drop_key(drop);
   const int on = dk.thr != 0;
+  VS_CHECK_ARG(!on || (unsigned long long)rows * (unsigned long long)cols < (1ull << 34),
+               "layernorm_bwd / grad_mask_cast: the dropout stream's group counter is 32 bits (rows * cols < 2^34)");
   const int grid = ln_grid(rows, false, cols);
 #define VS_LNB(V)                                                                                                        \
   do {                                                                                                                   \
