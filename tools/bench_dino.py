@@ -43,13 +43,20 @@ ops.PROFILE = []
 m.train_step(step_views(), 2, crit, opt, None, 0.996)
 torch.cuda.synchronize()
 recs, ops.PROFILE = ops.PROFILE, None
-hbm = {}
+hbm, fam = {}, {}
 for label, flops, e0, e1, nbytes in recs:
     if nbytes:
         h = hbm.setdefault(label, [0.0, 0.0, 0])
         h[0] += nbytes; h[1] += e0.elapsed_time(e1); h[2] += 1
+    elif flops:
+        f = fam.setdefault(label.split("[")[0].split(" ")[0], [0.0, 0.0, 0])
+        f[0] += flops; f[1] += e0.elapsed_time(e1); f[2] += 1
+fam = {k: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1), "ms_per_step": round(v[1], 3), "launches": v[2], "peak": 2500.0} for k, v in fam.items()}
+dom = max(fam.items(), key=lambda kv: kv[1]["ms_per_step"]) if fam else None
+roofline = None if dom is None else {"kernel": dom[0], "bound": "mfma", "achieved": dom[1]["tflops"], "peak": 2500.0, "unit": "TFLOP/s",
+                                     "frac": round(dom[1]["tflops"] / 2500.0, 4), "families": fam}
 hbm = {k: {"achieved_tbs": round(v[0] / (v[1] * 1e-3) / 1e12, 2), "peak_tbs": 8.0, "frac": round(v[0] / (v[1] * 1e-3) / 8e12, 3),
            "ms_per_step": round(v[1], 3), "launches": v[2]} for k, v in hbm.items()}
 print(json.dumps({"workload": f"ViT-B/16 DINO 2x224+8x96 K=65536 batch {B}" + (" from raw uint8 images (GPU multi-crop)" if a.raw else ""), "ms_per_step": round(dt * 1e3, 2),
                   "image_sets_per_s": round(B / dt, 1), "alg_tflops": round(437.8e9 * B / dt / 1e12, 1),
-                  "mfma_util": round(437.8e9 * B / dt / 2.5e15, 4), "loss": round(float(loss), 5), "hbm": hbm}))
+                  "mfma_util": round(437.8e9 * B / dt / 2.5e15, 4), "loss": round(float(loss), 5), "roofline": roofline, "hbm": hbm}))

@@ -24,4 +24,10 @@ run vit_s bench.py --model vit_s --steps 8 --warmup 3 --no-cpu-baseline --no-ker
 run vit_l bench.py --model vit_l --batch 128 --steps 8 --warmup 3 --no-cpu-baseline --no-kernel-timing
 run vit_l_fp8 bench.py --model vit_l --batch 128 --dtype fp8 --steps 8 --warmup 3 --no-cpu-baseline --no-kernel-timing
 run dino tools/bench_dino.py --steps 6 --warmup 2
+# the same lines as one JSON document (copy to profiles/<tag>_configs.json)
+python3 - "$log" "gpurun_out/${tag}_configs.json" <<'PY'
+import json, sys
+rows = [json.loads(l) for l in open(sys.argv[1]) if l.strip().startswith("{")]
+json.dump({"box": "one MI355X, one gpurun call", "configs": rows}, open(sys.argv[2], "w"), indent=1)
+PY
 cat $log
