@@ -40,7 +40,25 @@ __device__ unsigned long long* g_attn_stamps = nullptr;   // [workgroup][4] x 10
   } while (0)
 #endif
 
+// diagnostic builds only (tools/build_variant.sh): persistent forward without 1 = the arithmetic, 2 = the tile prefetch
+#ifndef ATTN_FWD_ABLATE
+#define ATTN_FWD_ABLATE 0
+#endif
+
 namespace {
+
+template <int V>
+struct IC2 {
+  static constexpr int value = V;
+};
+// f(IC2<0>{}), f(IC2<1>{}), ... f(IC2<N-1>{}): a loop whose index is a compile-time constant (asm immediates)
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(IC2<I>{});
+    static_for<N, I + 1>(f);
+  }
+}
 
 constexpr int DH = 64;
 constexpr int ROWB = DH * 2;  // bytes per tile row
@@ -345,6 +363,220 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const bf16_t* __re
     if (it == 0) ATTN_STAMP(2);
   }
   ATTN_STAMP(3);
+}
+
+// ------------------------------------------------------------------ forward, persistent (long sequences)
+// One 8-wave workgroup per CU walks the (batch, head) items b, b + G, ...; the K / V tiles of the NEXT item arrive by
+// LDS-DMA in the second tile buffer while the current item is computed, and its Q fragments are requested early too.
+// Why (round-2 stamps, B = 256, H = 12, N = 196, two 4-wave workgroups per CU): a workgroup waited 3.8 us for its K tile,
+// then ran two query passes of 6.8 + 4.8 us; the two co-resident workgroups hide only part of each other's waits
+// (7.7 us per item against 5.8 us of compute).  Here nqp <= 8 query pairs are one pass of the 8 waves and no wave ever
+// waits for a tile except in the first item.
+//
+// The transposed V reads are inline asm: for the ds_read_tr builtin (no memory operand) hipcc assumes a dependency on
+// every LDS-DMA in flight and would drain vmcnt(0) -- the next item's prefetch -- in front of each read (same finding as
+// csrc/gemm_tn.hip).  The item loop is unrolled by two so that every tile address is a compile-time offset.
+// the eight transposed reads of contraction step ST (rows 32 ST .. + 31) of a V tile: four column slices x (rows, rows + 16)
+template <int ST>
+__device__ __forceinline__ void tr_read_v4(s16x4 (&lo)[4], s16x4 (&hi)[4], const unsigned (&va)[4]) {
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo[dt]) : "v"(va[dt]), "n"(4096 * ST));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[dt]) : "v"(va[dt]), "n"(4096 * ST + 2048));
+  }
+}
+
+// QT = 16-query tiles per wave, 16 / QT waves per workgroup.  QT = 2: a K / V fragment read feeds two MFMAs, 8 waves of up
+// to 256 VGPRs; QT = 1: 16 waves of <= 128 VGPRs (four per SIMD) -- twice the LDS fragment traffic, but the kernel is bound
+// by waits, not by LDS or issue (rocprofv3 PMC of the QT = 2 form: waves parked in s_waitcnt / s_barrier 41 % of their
+// lifetime, issue stalls 29 %, issuing 30 %; matrix pipe 18 % busy), and four waves per SIMD cover each other's waits.
+template <int NS, int QT>
+__global__ __launch_bounds__(1024 / QT, QT == 1 ? 4 : 2) void attn_fwd_pers_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                                                float* __restrict__ lse, float* __restrict__ probs,
+                                                                                int N, int H, int nitems,
+                                                                                unsigned char* __restrict__ out8) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int Np = 32 * NS;
+  constexpr int NKT = 2 * NS;
+  constexpr int NW = 16 / QT;
+  constexpr int TILE = Np * ROWB;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const bool active = wave * 16 * QT < N;         // wave-uniform: this wave has at least one query
+  const long long stride = 3LL * H * DH;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 tail0 = key_mask_init(NKT - 2, g, N), tail1 = key_mask_init(NKT - 1, g, N);
+  int q[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) q[t] = (wave * QT + t) * 16 + li;
+  int item = blockIdx.x;
+  if (item >= nitems) return;
+
+  auto q_base = [&](int it) { return qkv + (long long)(it / H) * N * stride + (it % H) * DH; };
+  auto issue_tiles = [&](int it, char* kt, char* vt) {
+    const bf16_t* qg = q_base(it);
+    dma_tile<NW>(kt, qg + (long long)H * DH, stride, N, Np, wave, lane);
+    dma_tile<NW>(vt, qg + 2LL * H * DH, stride, N, Np, wave, lane);
+  };
+  // Every vector-memory instruction of an item is issued by every wave that has queries, unconditionally (rows >= N fall
+  // outside the buffer descriptors: loads return 0, stores are dropped), so the number of operations behind the prefetch
+  // is a constant and the wait at the top of the next item can leave the output stores in flight (counted vmcnt).
+  const unsigned q_bytes = (unsigned)((long long)(N - 1) * stride * 2 + ROWB);
+  auto load_q = [&](int it, bf16x8 (&qq)[QT][2]) {
+    __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)q_base(it), 0, (int)q_bytes, 0x00020000);
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        qq[t][kk] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                                   rq, (unsigned)((long long)q[t] * stride * 2 + 64 * kk + 16 * g), 0, 0));
+  };
+  constexpr unsigned OOB = 0x80000000u;
+  const unsigned out_bytes = (unsigned)((long long)N * H * DH * 2);
+  // transposed V fragment addresses of this lane (tile-relative), as in tr_frag: row 32 st + 4 g + q (+ 16), column slice
+  // dt.  The swizzle of a row depends on (row >> 1) & 3 only, which 32 st and + 16 leave alone: four per-lane bases (one
+  // per dt) and the immediates 4096 st (+ 2048) address every read.
+  unsigned vrel[4];
+  {
+    const int tq = (lane >> 2) & 3, tpp = lane & 3;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) vrel[dt] = (unsigned)(tile_off(4 * g + tq, 2 * dt + (tpp >> 1)) + 8 * (tpp & 1));
+  }
+
+  bf16x8 qn[QT][2];
+  issue_tiles(item, smem, smem + TILE);
+  load_q(item, qn);
+  bool first = true;
+
+  auto one_item = [&](auto cur_c) {
+    constexpr int cur = decltype(cur_c)::value;
+    const char* Kt = smem + cur * 2 * TILE;
+    const char* Vt = Kt + TILE;
+    char* Kn = smem + (cur ^ 1) * 2 * TILE;
+    const int b = item / H, h = item - b * H;
+    const int next = item + (int)gridDim.x;
+    const bool has_next = next < nitems;            // workgroup-uniform
+    // this item's tiles (every wave's share) have landed; every wave is done with the other buffer.  The BUILTIN wait (not
+    // inline asm): hipcc then knows that the Q loads of this item are complete too, and does not drain the prefetch issued
+    // below in front of their first use (s_waitcnt vmcnt(n) alone: expcnt 7, lgkmcnt 15 = 0x0F70 | n)
+    if (probs || first || !active) __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0) (a wave without queries issues no stores)
+    else if (out8) __builtin_amdgcn_s_waitcnt(0x0F70 | (QT * 7));  // the previous item's QT x (1 + 2 + 4) stores may still be in flight
+    else __builtin_amdgcn_s_waitcnt(0x0F70 | (QT * 3));            // ... QT x (1 lse + 2 output rows halves)
+    first = false;
+    __builtin_amdgcn_s_barrier();
+    bf16x8 qf[QT][2];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      qf[t][0] = qn[t][0];
+      qf[t][1] = qn[t][1];
+    }
+    if (has_next && ATTN_FWD_ABLATE != 2) {
+      issue_tiles(next, Kn, Kn + TILE);
+      load_q(next, qn);
+    }
+    if (active && ATTN_FWD_ABLATE != 1) {
+      f32x4 sc[QT][NKT];
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        const bf16x8 k0 = lds_frag(Kt, kt * 16 + li, 0, lane);
+        const bf16x8 k1 = lds_frag(Kt, kt * 16 + li, 1, lane);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) sc[t][kt] = MFMA16(k0, qf[t][0], kt == NKT - 2 ? tail0 : (kt == NKT - 1 ? tail1 : zero4));
+#pragma unroll
+        for (int t = 0; t < QT; ++t) sc[t][kt] = MFMA16(k1, qf[t][1], sc[t][kt]);
+      }
+      float m[QT], sum[QT], inv[QT];
+#pragma unroll
+      for (int t = 0; t < QT; ++t) softmax_tile<NKT>(sc[t], m[t], sum[t]);
+      __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)(lse + ((long long)b * H + h) * N), 0, N * 4, 0x00020000);
+#pragma unroll
+      for (int t = 0; t < QT; ++t) {
+        inv[t] = 1.0f / sum[t];
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m[t] * SCALE + __logf(sum[t])), rl, g == 0 ? (unsigned)q[t] * 4u : OOB, 0, 0);
+        if (probs && q[t] < N) {
+          float* pr = probs + (((long long)b * H + h) * N + q[t]) * N;
+#pragma unroll
+          for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int key = kt * 16 + 4 * g + r;
+              if (key < N) pr[key] = sc[t][kt][r] * inv[t];
+            }
+        }
+      }
+      f32x4 o[QT][4];
+#pragma unroll
+      for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const unsigned vbase = (unsigned)(size_t)LDS_PTR(Vt);
+      unsigned va[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) va[dt] = vbase + vrel[dt];
+      // transposed V reads one contraction step ahead of the MFMAs that consume them (two register sets, counted lgkmcnt)
+      // (QT = 2 only: with four waves per SIMD the other waves cover the read latency and the registers are not there)
+      constexpr int SETS = QT == 2 ? 2 : 1;
+      s16x4 lo[SETS][4], hi[SETS][4];
+      if constexpr (SETS == 2) tr_read_v4<0>(lo[0], hi[0], va);
+      static_for<NS>([&](auto st_c) {
+        constexpr int st = decltype(st_c)::value;
+        constexpr int set = SETS == 2 ? (st & 1) : 0;
+        bf16x8 pf[QT];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) pf[t] = pack_frag(sc[t][2 * st], sc[t][2 * st + 1]);
+        if constexpr (SETS == 1) {
+          tr_read_v4<st>(lo[0], hi[0], va);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if constexpr (st + 1 < NS) {
+          tr_read_v4<st + 1>(lo[set ^ 1], hi[set ^ 1], va);
+          asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");      // the 8 reads just issued may stay in flight
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          typedef __attribute__((ext_vector_type(8))) short s16x8;
+          const s16x8 v = {lo[set][dt][0], lo[set][dt][1], lo[set][dt][2], lo[set][dt][3], hi[set][dt][0], hi[set][dt][1], hi[set][dt][2], hi[set][dt][3]};
+          const bf16x8 vf = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+          for (int t = 0; t < QT; ++t) o[t][dt] = MFMA16(vf, pf[t], o[t][dt]);
+        }
+      });
+      __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (long long)b * N * (H * DH)), 0, (int)out_bytes, 0x00020000);
+#pragma unroll
+      for (int t = 0; t < QT; ++t) {
+        const unsigned rowoff = (unsigned)q[t] * (unsigned)(H * DH * 2) + (unsigned)(h * DH * 2);    // beyond out_bytes for q >= N
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          const u32x2 w0 = pack4(o[t][2 * pr] * inv[t]), w1 = pack4(o[t][2 * pr + 1] * inv[t]);
+          auto lo2 = __builtin_amdgcn_permlane16_swap(w0[0], w1[0], false, false);
+          auto hi2 = __builtin_amdgcn_permlane16_swap(w0[1], w1[1], false, false);
+          const int odd = g & 1;
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo2[0], hi2[0], lo2[1], hi2[1]}, ro,
+                                                 rowoff + (unsigned)(((2 * pr + odd) * 16 + 4 * (g - odd)) * 2), 0, 0);
+        }
+      }
+      if (out8) {
+        __amdgpu_buffer_rsrc_t r8 = __builtin_amdgcn_make_buffer_rsrc((void*)(out8 + (long long)b * N * (H * DH)), 0, (int)(out_bytes / 2), 0x00020000);
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            const f32x4 v = o[t][dt] * inv[t];
+            __builtin_amdgcn_raw_buffer_store_b32(pack_fp8x4(v[0], v[1], v[2], v[3]), r8,
+                                                  (unsigned)q[t] * (unsigned)(H * DH) + (unsigned)(h * DH + 4 * g + 16 * dt), 0, 0);
+          }
+      }
+    }
+    item = next;
+    return has_next;
+  };
+  for (;;) {
+    if (!one_item(IC2<0>{})) break;
+    if (!one_item(IC2<1>{})) break;
+  }
 }
 
 // ------------------------------------------------------------------ backward: dK, dV
@@ -863,9 +1095,38 @@ int ensure_lds(K kernel, int bytes, bool* done, const char* who) {
   return VITSSL_OK;
 }
 
+// 2 (default): sequences of more than 128 tokens run the persistent forward with 8 waves x two query tiles; 1: 16 waves x one
+// query tile (same speed within 1-2 %, a few spilled registers at N > 224); 0: the two-workgroups-per-CU kernel
+// (VITSSL_ATTN_FWD_PERSIST, developer knob for A/B timing)
+int attn_fwd_persist() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("VITSSL_ATTN_FWD_PERSIST");
+    v = e ? atoi(e) : 2;
+  }
+  return v;
+}
+
 template <int NS>
 int launch_fwd(const bf16_t* qkv, bf16_t* out, float* lse, float* probs, int B, int N, int H, hipStream_t s,
                unsigned char* out8 = nullptr) {
+  if constexpr (NS >= 5) {
+    if (attn_fwd_persist()) {
+      static bool done_p1 = false, done_p2 = false;
+      const int lds_p = 4 * NS * 32 * ROWB;            // two (K, V) tile pairs
+      const int nitems = B * H;
+      const int grid = nitems < attn_cu_count() ? nitems : attn_cu_count();
+      if (attn_fwd_persist() == 2) {                   // 8 waves x two query tiles
+        if (int rc = ensure_lds(attn_fwd_pers_kernel<NS, 2>, lds_p, &done_p2, "attn_fwd_pers")) return rc;
+        hipLaunchKernelGGL((attn_fwd_pers_kernel<NS, 2>), dim3(grid), dim3(512), lds_p, s, qkv, out, lse, probs, N, H, nitems, out8);
+      } else {                                         // 16 waves x one query tile (A/B)
+        if (int rc = ensure_lds(attn_fwd_pers_kernel<NS, 1>, lds_p, &done_p1, "attn_fwd_pers")) return rc;
+        hipLaunchKernelGGL((attn_fwd_pers_kernel<NS, 1>), dim3(grid), dim3(1024), lds_p, s, qkv, out, lse, probs, N, H, nitems, out8);
+      }
+      VS_CHECK_LAUNCH("attn_fwd_pers");
+      return VITSSL_OK;
+    }
+  }
   static bool done = false;
   const int lds = 2 * NS * 32 * ROWB;
   constexpr int NW = NS <= 2 ? 2 : 4;
