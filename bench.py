@@ -153,6 +153,8 @@ def main():
     torch.cuda.set_device(dev)                               # bind the GPU before RCCL sees the process
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        from vitssl_hip.engine import configure_collectives
+        configure_collectives()                              # RCCL channels <= the CUs the persistent GEMM grids leave alone
         kw = {"device_id": dev} if args.backend == "nccl" else {}
         dist.init_process_group(args.backend, rank=rank, world_size=world, **kw)
 

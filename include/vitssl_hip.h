@@ -289,7 +289,9 @@ int vitssl_weightnorm_bwd(const float* dw, const float* g, const float* v, const
                           int D, void* stream);
 /* DINOLoss: teacher f32 [G,B,K], student f32 [V,B,K], center f32 [K];
  * loss_sum += -(1/(G B K)) sum_{b,k} (sum_g softmax((t-c)/tt))(sum_v log_softmax(s/ts));
- * dstudent bf16 [V,B,K] = gscale * dloss/dstudent (or NULL); t_ws f32 [B,K] scratch. */
+ * dstudent bf16 [V,B,K] = gscale * dloss/dstudent (or NULL); t_ws f32 scratch of B*K + VITSSL_DINO_TWS_EXTRA(G,B) floats
+ * ([B,K] teacher probabilities, then the per-slice softmax statistics of the teacher rows). */
+#define VITSSL_DINO_TWS_EXTRA(G, B) (8 * (G) * (B))
 int vitssl_dino_loss(const float* teacher, const float* student, const float* center, float* t_ws, float* loss_sum,
                      void* dstudent_bf16, int G, int V, int B, int K, float teacher_temp, float student_temp, float gscale,
                      void* stream);

@@ -390,3 +390,15 @@ def test_setup_device_binds_local_rank(monkeypatch):
     monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
     with pytest.raises(RuntimeError, match="no GPU visible"):
         train_utils.setup_device()
+
+
+def test_configure_collectives_caps_channels_at_the_reserve(monkeypatch):
+    """RCCL runs one workgroup per channel; the persistent GEMM grids leave `reserve` CUs free, so the channel count is
+    capped there unless the user chose otherwise (engine.configure_collectives, called before init_process_group)."""
+    from vitssl_hip import engine
+    monkeypatch.delenv("NCCL_MAX_NCHANNELS", raising=False)
+    monkeypatch.delenv("NCCL_MIN_NCHANNELS", raising=False)
+    assert engine.configure_collectives() == {"NCCL_MAX_NCHANNELS": "8", "NCCL_MIN_NCHANNELS": "8"}
+    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "32")
+    monkeypatch.delenv("NCCL_MIN_NCHANNELS")
+    assert engine.configure_collectives(16) == {"NCCL_MAX_NCHANNELS": "32", "NCCL_MIN_NCHANNELS": "16"}   # the user's choice wins

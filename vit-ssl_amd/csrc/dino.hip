@@ -235,6 +235,72 @@ __global__ __launch_bounds__(DR_THREADS) void dino_teacher_reg_kernel(const floa
   }
 }
 
+// ---- teacher half on the whole chip ---------------------------------------------------------------------------------
+// dino_teacher_reg_kernel runs ONE workgroup per batch element (64 of 256 CUs at the bench's batch, 63 us per step, round-2
+// profile).  Two small launches over row SLICES instead: (1) every (teacher row, slice) workgroup reduces its K / DT_SLICES
+// columns to (max, sum of exp), (2) every (batch element, slice) workgroup combines the slices' statistics of each global
+// view's row, recomputes its columns and writes T = sum_g softmax once.  The logits are read twice (2 x G B K floats,
+// L2 / Infinity-Cache resident the second time) for 4 x the workgroups.
+constexpr int DT_SLICES = 4;
+
+template <int NVS>     // float4 per thread per slice: K / (4 * 1024 * DT_SLICES)
+__global__ __launch_bounds__(DR_THREADS) void dino_teacher_stats_kernel(const float* __restrict__ teacher, const float* __restrict__ center,
+                                                                        float* __restrict__ stats, int K, float inv_tau) {
+  __shared__ float red[DR_THREADS / 64];
+  const int row = blockIdx.x / DT_SLICES, sl = blockIdx.x - row * DT_SLICES;
+  const float* tr = teacher + (long long)row * K + (long long)sl * (K / DT_SLICES);
+  const float* cr = center + (long long)sl * (K / DT_SLICES);
+  f32x4 x[NVS];
+  float m = -INFINITY;
+#pragma unroll
+  for (int v = 0; v < NVS; ++v) {
+    const int k = 4 * (threadIdx.x + DR_THREADS * v);
+    x[v] = (*(const f32x4*)(tr + k) - *(const f32x4*)(cr + k)) * inv_tau;
+    m = fmaxf(fmaxf(m, fmaxf(x[v][0], x[v][1])), fmaxf(x[v][2], x[v][3]));
+  }
+  m = block_reduce16(m, red, true);
+  float s = 0.f;
+#pragma unroll
+  for (int v = 0; v < NVS; ++v) s += (__expf(x[v][0] - m) + __expf(x[v][1] - m)) + (__expf(x[v][2] - m) + __expf(x[v][3] - m));
+  s = block_reduce16(s, red, false);
+  if (threadIdx.x == 0) {
+    stats[2 * blockIdx.x] = m;
+    stats[2 * blockIdx.x + 1] = s;
+  }
+}
+
+template <int NVS>
+__global__ __launch_bounds__(DR_THREADS) void dino_teacher_norm_kernel(const float* __restrict__ teacher, const float* __restrict__ center,
+                                                                       const float* __restrict__ stats, float* __restrict__ T, int G,
+                                                                       int B, int K, float inv_tau) {
+  const int b = blockIdx.x / DT_SLICES, sl = blockIdx.x - b * DT_SLICES;
+  const long long col0 = (long long)sl * (K / DT_SLICES);
+  f32x4 acc[NVS];
+#pragma unroll
+  for (int v = 0; v < NVS; ++v) acc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int g = 0; g < G; ++g) {
+    const float* st = stats + 2 * ((long long)g * B + b) * DT_SLICES;
+    float m = st[0];
+#pragma unroll
+    for (int j = 1; j < DT_SLICES; ++j) m = fmaxf(m, st[2 * j]);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < DT_SLICES; ++j) s += st[2 * j + 1] * __expf(st[2 * j] - m);
+    const float inv = 1.0f / s;
+    const float* tr = teacher + ((long long)g * B + b) * K + col0;
+#pragma unroll
+    for (int v = 0; v < NVS; ++v) {
+      const int k = 4 * (threadIdx.x + DR_THREADS * v);
+      const f32x4 x = (*(const f32x4*)(tr + k) - *(const f32x4*)(center + col0 + k)) * inv_tau;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[v][r] += __expf(x[r] - m) * inv;
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < NVS; ++v) *(f32x4*)(T + (long long)b * K + col0 + 4 * (threadIdx.x + DR_THREADS * v)) = acc[v];
+}
+
 template <int NV>
 __global__ __launch_bounds__(DR_THREADS) void dino_student_reg_kernel(const float* __restrict__ student, const float* __restrict__ T,
                                                                       float* __restrict__ loss_sum, bf16_t* __restrict__ dstudent, int G,
@@ -395,8 +461,18 @@ extern "C" int vitssl_dino_loss(const float* teacher, const float* student, cons
   const int nv = (K % 4096 == 0) ? K / 4096 : 0;
 #define VS_DINO_REG(NV)                                                                                                            \
   do {                                                                                                                             \
-    hipLaunchKernelGGL(dino_teacher_reg_kernel<NV>, dim3(B), dim3(DR_THREADS), 0, s, teacher, center, t_ws, G, B, K, 1.0f / teacher_temp); \
-    VS_CHECK_LAUNCH("dino_teacher");                                                                                               \
+    if constexpr (NV % DT_SLICES == 0) {                                                                                           \
+      float* stats = t_ws + (long long)B * K;     /* [G, B, DT_SLICES, 2] behind T: see the header */                               \
+      hipLaunchKernelGGL(dino_teacher_stats_kernel<NV / DT_SLICES>, dim3(G * B * DT_SLICES), dim3(DR_THREADS), 0, s, teacher, center,  \
+                         stats, K, 1.0f / teacher_temp);                                                                           \
+      VS_CHECK_LAUNCH("dino_teacher_stats");                                                                                       \
+      hipLaunchKernelGGL(dino_teacher_norm_kernel<NV / DT_SLICES>, dim3(B * DT_SLICES), dim3(DR_THREADS), 0, s, teacher, center,      \
+                         stats, t_ws, G, B, K, 1.0f / teacher_temp);                                                               \
+      VS_CHECK_LAUNCH("dino_teacher_norm");                                                                                        \
+    } else {                                                                                                                       \
+      hipLaunchKernelGGL(dino_teacher_reg_kernel<NV>, dim3(B), dim3(DR_THREADS), 0, s, teacher, center, t_ws, G, B, K, 1.0f / teacher_temp); \
+      VS_CHECK_LAUNCH("dino_teacher");                                                                                             \
+    }                                                                                                                              \
     hipLaunchKernelGGL(dino_student_reg_kernel<NV>, dim3(V * B), dim3(DR_THREADS), 0, s, student, t_ws, loss_sum,                     \
                        (bf16_t*)dstudent_bf16, G, B, K, 1.0f / student_temp, gscale);                                              \
     VS_CHECK_LAUNCH("dino_student");                                                                                               \

@@ -35,7 +35,8 @@ struct TnParams {
   int N1, N2;
   int tiles1, tiles2, splits;
   int chunks_per_split;   // in units of TN_KM rows
-  float* slabs;           // [splits][N1][N2] fp32 or nullptr (atomic mode)
+  float* slabs;           // [splits][N1][N2] fp32 or nullptr (atomic mode, or direct mode)
+  int direct;             // splits == 1: every C tile has exactly one owner, which adds its result into C itself (no slab, no reduce pass)
 };
 
 __device__ __forceinline__ int tn_f(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
@@ -149,6 +150,8 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(TnParams p) {
       float* q = dst + (long long)n1 * p.N2 + n2;
       if (p.slabs) {
         *(f32x4*)q = acc[i][j];
+      } else if (p.direct) {
+        *(f32x4*)q = *(const f32x4*)q + acc[i][j];
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) unsafeAtomicAdd(q + r, acc[i][j][r]);
@@ -470,6 +473,8 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_pp_kernel(TnParams p) {
       float* q = dst + (long long)n1 * p.N2 + n2;
       if (p.slabs) {
         *(f32x4*)q = acc[i][j];
+      } else if (p.direct) {
+        *(f32x4*)q = *(const f32x4*)q + acc[i][j];
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) unsafeAtomicAdd(q + r, acc[i][j][r]);
@@ -498,6 +503,7 @@ struct Tn8Params {
   int tiles1, tiles2, splits;
   int chunks_per_split;   // in units of TN8_KM rows
   float* slabs;
+  int direct;             // as TnParams::direct
   const float* alpha;     // device scalars multiplied into the result (dequantisation of the two operands), or NULL
   const float* alpha2;
 };
@@ -635,6 +641,8 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_fp8_kernel(Tn8Params p)
       const f32x4 v = acc[i][j] * al;
       if (p.slabs) {
         *(f32x4*)q = v;
+      } else if (p.direct) {
+        *(f32x4*)q = *(const f32x4*)q + v;
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) unsafeAtomicAdd(q + r, v[r]);
@@ -691,6 +699,11 @@ extern "C" int vitssl_gemm_bf16_tn(const void* A, const void* B, float* C, int64
   const long long need = (long long)p.splits * N1 * N2;
   p.slabs = (workspace && workspace_floats >= need) ? workspace : nullptr;
   VS_CHECK_ARG(!workspace || p.slabs, "gemm_tn: workspace too small (%lld < %lld floats)", (long long)workspace_floats, need);
+  // One split (more C tiles than CUs: the DINO head's [65536, 768] weight gradient): the slab would be written, read back and
+  // added to C by a second kernel -- 3 x 201 MB for nothing, since every tile has a single owner (tn_reduce was 1.6 ms of a
+  // DINO step, 114 us per such call).  The owner adds into C itself.
+  p.direct = p.splits == 1;
+  if (p.direct) p.slabs = nullptr;
   static bool attr_done = false;
   static int use_pp = -1;                              // VITSSL_TN_PP=0: the two-phase loop (developer knob)
   if (use_pp < 0) {
@@ -750,6 +763,8 @@ extern "C" int vitssl_gemm_fp8_tn(const void* A8, const void* B8, float* C, int6
   const long long need = (long long)p.splits * N1 * N2;
   p.slabs = (workspace && workspace_floats >= need) ? workspace : nullptr;
   VS_CHECK_ARG(!workspace || p.slabs, "gemm_fp8_tn: workspace too small (%lld < %lld floats)", (long long)workspace_floats, need);
+  p.direct = p.splits == 1;
+  if (p.direct) p.slabs = nullptr;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_fp8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);

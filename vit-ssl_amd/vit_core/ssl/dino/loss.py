@@ -19,7 +19,7 @@ class _DinoLossFn(Function):
         s2 = R.as_f32(student).reshape(V * B, K)
         c = R.as_f32(center.detach()).reshape(-1)
         dev = s2.device
-        t_ws = torch.empty(B, K, dtype=F32, device=dev)
+        t_ws = torch.empty(ops.dino_tws_floats(G, B, K), dtype=F32, device=dev)
         loss = torch.zeros(1, dtype=F32, device=dev)
         dstudent = torch.empty(V * B, K, dtype=BF16, device=dev) if student.requires_grad else None
         ops.dino_loss(t2, s2, c, t_ws, loss, dstudent, G, V, B, K, t_temp, s_temp, 1.0)

@@ -249,7 +249,7 @@ class DINOViT(nn.Module):
             dev = student.device
             loss = rt.ws.get("loss", (1,), F32, dev)
             loss.zero_()
-            t_ws = rt.ws.get("t_ws", (B, K), F32, dev)
+            t_ws = rt.ws.get("t_ws", (ops.dino_tws_floats(G, B, K),), F32, dev)
             dstudent = rt.ws.get("dstudent", (V * B, K), BF16, dev)
             ops.dino_loss(teacher, student, self.center.view(-1), t_ws, loss, dstudent, G, V, B, K,
                           float(criterion.teacher_temp), float(criterion.student_temp), 1.0)

@@ -230,6 +230,26 @@ class FlatStore:
         return self._fp8[key + ".T"], self._fp8_plan.alpha[j:j + 1]
 
 
+RESERVED_CUS_DEFAULT = 8
+
+
+def configure_collectives(reserve_cus: int = RESERVED_CUS_DEFAULT):
+    """Size the collective library to the CUs the persistent GEMM grids leave alone.  Call BEFORE
+    torch.distributed.init_process_group (RCCL reads its environment when the communicator is built).
+
+    RCCL launches one workgroup per channel and a ring only progresses while all of them are resident.  RCCL 2.26 on
+    gfx950 sets up 128 collective channels (tools/rccl_probe.py, NCCL_DEBUG=INFO, one MI355X); with the GEMM grids holding
+    every other CU for a whole kernel, a collective of more channels than reserved CUs would only start at kernel
+    boundaries.  So the channel count is capped at the reserve (unless the user has set NCCL_MAX_NCHANNELS): 8 channels
+    move the 345 MB of ViT-B gradients (604 MB per GPU through the ring) well inside one backward pass.
+    Returns the values in force."""
+    if "NCCL_MAX_NCHANNELS" not in _os.environ:
+        _os.environ["NCCL_MAX_NCHANNELS"] = str(max(1, int(reserve_cus)))
+    if "NCCL_MIN_NCHANNELS" not in _os.environ:
+        _os.environ["NCCL_MIN_NCHANNELS"] = str(min(int(_os.environ["NCCL_MAX_NCHANNELS"]), max(1, int(reserve_cus))))
+    return {k: _os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS")}
+
+
 class GradReducer:
     """Data-parallel gradient averaging over RCCL (torch.distributed 'nccl' on ROCm),
     overlapped with backward: the engine calls `ready(lo, hi)` as soon as a contiguous
@@ -238,7 +258,7 @@ class GradReducer:
     folded into the optimizer kernel.  On CPU tensors (gloo, tests) it runs inline."""
 
     def __init__(self, gflat: torch.Tensor, group=None, bucket_mb: float = 32.0, expect: Optional[Tuple[int, int]] = None,
-                 reserve_cus: int = 8):
+                 reserve_cus: int = RESERVED_CUS_DEFAULT):
         """`expect` = (lo, hi) range of the flat buffer that one backward must hand over exactly once
         (default: the whole buffer); finish() checks it, so a schedule change that forgets or repeats a
         range fails loudly on one GPU instead of silently de-synchronising replicas on eight."""
