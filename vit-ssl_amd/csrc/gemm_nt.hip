@@ -207,7 +207,11 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
                                             const int wm, const int wn, const int lane, const char* lds = nullptr) {
   constexpr int MI = CFG::MI;
   // GLUT_OFF >= 0: LDS byte offset of the GELU table minus GLUT_LO8 (the ds_read's immediate)
-  constexpr bool GLUT = EPI == VITSSL_EPI_GELU && GLUT_OFF >= 0 && NT_ABLATE == 0 && !Q8;   // (the e4m3 image is quantised from fp32)
+  constexpr bool GLUT = EPI == VITSSL_EPI_GELU && GLUT_OFF >= 0 && NT_ABLATE == 0;
+  // fp8 operands: the table's entries are (bf16 s gelu'(u)) | (e4m3(s gelu(u) qs) << 16) -- the e4m3 byte is quantised from
+  // the fp32 value when the table is built, exactly as the arithmetic path does per element -- and serve launches that
+  // write the g' image and the e4m3 image only (no bf16 `a`, no amax: what engine.EncoderStack asks for); launch-uniform
+  const bool glut_on = GLUT && (!Q8 || (p.out1 == nullptr && p.qamax == nullptr));
   // ------------------------------------------------------------------ epilogue
   // All global traffic of the epilogue goes through raw buffer instructions on a window
   // that starts at the tile's first row: rows past M fall outside num_records and columns
@@ -442,7 +446,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
       // GELU by table: the row's 16 lookups are issued first and fly under the dropout-stream arithmetic below
       unsigned gl[16];                  // (bf16 s gelu(u)) | (bf16 s gelu'(u)) << 16 per element: [jp][h][r]
       bool gslow[2][2];                 // wave-uniform: some lane of this group is outside the table's range
-      if constexpr (GLUT) {
+      if (GLUT && glut_on) {
 #pragma unroll
         for (int jp = 0; jp < 2; ++jp)
 #pragma unroll
@@ -484,12 +488,20 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
           }
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
-            if (GLUT && !gslow[jp][h]) {
+            if (GLUT && glut_on && !gslow[jp][h]) {
               const int q = 8 * jp + 4 * h;
-              out_b[jp][h] = u32x2{__builtin_amdgcn_perm(gl[q + 1], gl[q], 0x05040100u) & km[h][0],
-                                   __builtin_amdgcn_perm(gl[q + 3], gl[q + 2], 0x05040100u) & km[h][1]};
-              out_a[jp][h] = u32x2{__builtin_amdgcn_perm(gl[q + 1], gl[q], 0x07060302u) & km[h][0],
-                                   __builtin_amdgcn_perm(gl[q + 3], gl[q + 2], 0x07060302u) & km[h][1]};
+              if constexpr (!Q8) {
+                out_b[jp][h] = u32x2{__builtin_amdgcn_perm(gl[q + 1], gl[q], 0x05040100u) & km[h][0],
+                                     __builtin_amdgcn_perm(gl[q + 3], gl[q + 2], 0x05040100u) & km[h][1]};
+                out_a[jp][h] = u32x2{__builtin_amdgcn_perm(gl[q + 1], gl[q], 0x07060302u) & km[h][0],
+                                     __builtin_amdgcn_perm(gl[q + 3], gl[q + 2], 0x07060302u) & km[h][1]};
+              } else {
+                out_a[jp][h] = u32x2{__builtin_amdgcn_perm(gl[q + 1], gl[q], 0x05040100u) & km[h][0],
+                                     __builtin_amdgcn_perm(gl[q + 3], gl[q + 2], 0x05040100u) & km[h][1]};
+                // the four e4m3 bytes (byte 2 of every entry) and the byte mask of the kept elements
+                const unsigned b01 = __builtin_amdgcn_perm(gl[q + 1], gl[q], 0x0c0c0602u), b23 = __builtin_amdgcn_perm(gl[q + 3], gl[q + 2], 0x06020c0cu);
+                out_q[jp][h] = (b01 | b23) & __builtin_amdgcn_perm(km[h][1], km[h][0], 0x06040200u);
+              }
               continue;
             }
             float y[4], d[4];
@@ -855,7 +867,7 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_nt_pp_kernel(NtParams p)
   constexpr int DUMMY = 2 * BUF;                       // 1 KiB sink for the slots a short A1 unit does not need
   constexpr unsigned OOBV = 0x80000000u;
   // EPI_GELU (bf16 operands): the 18 KiB GELU table sits behind the sink (see "GELU by table" above nt_epilogue)
-  constexpr bool USE_GLUT = EPI == VITSSL_EPI_GELU && !F8 && NT_ABLATE == 0 && NT_GELU_LUT;
+  constexpr bool USE_GLUT = EPI == VITSSL_EPI_GELU && NT_ABLATE == 0 && NT_GELU_LUT;
   constexpr int GLUT_BASE = 2 * BUF + 1024;
   constexpr int GLUT_IMM = USE_GLUT ? GLUT_BASE - (int)GLUT_LO8 : -1;
   static_assert(!USE_GLUT || (GLUT_IMM >= 0 && GLUT_IMM < 65536), "the table's offset must fit the ds_read immediate");
@@ -1121,7 +1133,12 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_nt_pp_kernel(NtParams p)
       const unsigned h = (unsigned)((e >> 1) + (GLUT_E_LO << 7)) | ((unsigned)(e & 1) << 15);
       float y, dy;
       gelu_both_scaled(bf2f((bf16_t)h), hs, cs, y, dy);
-      tab[e] = (unsigned)f2bf(y) | ((unsigned)f2bf(dy) << 16);
+      if constexpr (F8) {
+        const float qs = p.qscale ? *p.qscale : 1.0f;
+        tab[e] = (unsigned)f2bf(dy) | ((pack_fp8x4(y * qs, 0.f, 0.f, 0.f) & 0xffu) << 16);
+      } else {
+        tab[e] = (unsigned)f2bf(y) | ((unsigned)f2bf(dy) << 16);
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
@@ -1193,7 +1210,7 @@ int nt_pp_enabled() {
 
 template <int EPI, typename CFG, bool F8 = false>
 int launch_pp(NtParams p, hipStream_t s) {
-  constexpr int LDS = 2 * CFG::BUF_BYTES + 1024 + ((EPI == VITSSL_EPI_GELU && !F8 && NT_ABLATE == 0 && NT_GELU_LUT) ? GLUT_BYTES : 0);
+  constexpr int LDS = 2 * CFG::BUF_BYTES + 1024 + ((EPI == VITSSL_EPI_GELU && NT_ABLATE == 0 && NT_GELU_LUT) ? GLUT_BYTES : 0);
   static bool attr_done = false;  // idempotent; a benign race sets the same value
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, CFG, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
