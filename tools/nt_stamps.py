@@ -45,7 +45,8 @@ def main():
     stamps = torch.zeros(256 * 2 * 16 * 4, dtype=torch.int64, device=dev)
     for (N, K) in [(3072, 768), (768, 768), (768, 3072)]:
         A, B = rb(M, K), rb(N, K)
-        bias = torch.randn(N, device=dev)
+        B = (B.float() * (4.0 / K ** 0.5)).to(torch.bfloat16)     # outputs ~ N(0, 1), like a model's pre-activations
+        bias = torch.randn(N, device=dev) * 0.1
         o16 = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
         o16b = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
         o32 = torch.randn(M, N, device=dev)

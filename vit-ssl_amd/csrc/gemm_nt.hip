@@ -64,6 +64,13 @@
 #ifndef NT_GELU_LUT
 #define NT_GELU_LUT 1
 #endif
+// rows (16-row MFMA tiles) whose residual / g' operands are requested together in the RESID / DGELU epilogues
+#ifndef NT_RG_RESID
+#define NT_RG_RESID 1
+#endif
+#ifndef NT_RG_DGELU
+#define NT_RG_DGELU 2
+#endif
 // diagnostic builds only (tools/build_variant.sh): 1 = epilogue arithmetic and loads but NO stores,
 // 2 = stores but no GELU / dropout arithmetic and no residual / g' loads
 #ifndef NT_ABLATE
@@ -375,10 +382,14 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
   // (pair-major order left them half an epilogue apart and the second bf16 image of the GELU
   // epilogue was written at ~3 TB/s).  The residual / g' operands of a whole group are
   // loaded before its first use.
-  constexpr int RG = MI % 2 != 0 ? 1 : ((EPI == VITSSL_EPI_RESID || MI % 4 != 0) ? 2 : 4);
-  static_assert(MI % RG == 0, "row groups must tile the wave's rows");
+  // Rows per group: the group's loads are one memory round trip.  The 224-row tiles (MI = 7: every N = 768 launch of ViT-B,
+  // both residual epilogues among them) take ONE row per group.  Round 3 measured uneven groups (4 + 3) against that,
+  // interleaved: N = K = 768 residual 104 -> 109 us, K = 3072 residual 251 -> 247 us, dGELU unchanged -- the phase is
+  // bound by bytes, not by round trips (as round 1 found for MI = 8); NT_RG_RESID / NT_RG_DGELU keep the experiment.
+  constexpr int RG = EPI == VITSSL_EPI_RESID ? (MI % 2 == 0 ? 2 : NT_RG_RESID) : (EPI == VITSSL_EPI_DGELU ? (MI % 4 == 0 ? 4 : NT_RG_DGELU) : 4);
 #pragma unroll
   for (int ig = 0; ig < MI; ig += RG) {
+    const int cnt = MI - ig < RG ? MI - ig : RG;      // (a constant once the loop is unrolled)
     f32x4 res[RG][2][2];     // RESID: residual stream
     u32x2 gpre[RG][2][2];    // DGELU: g' in accumulator layout
     if constexpr (EPI == VITSSL_EPI_RESID) {
@@ -386,6 +397,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
       for (int ii = 0; ii < RG; ++ii)
 #pragma unroll
         for (int jp = 0; jp < 2; ++jp) {
+          if (ii >= cnt) continue;
           if (NT_ABLATE == 2) {
             res[ii][jp][0] = res[ii][jp][1] = f32x4{0.f, 0.f, 0.f, 0.f};
           } else if (NT_ROWS128) {
@@ -407,6 +419,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
         u32x4 raw[RG][2];
 #pragma unroll
         for (int ii = 0; ii < RG; ++ii) {
+          if (ii >= cnt) continue;
           if (NT_ROWS128) {
             const u32x4 l1 = __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_bf16_line(ig + ii, 0), 0, 0);
             const u32x4 l2 = __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_bf16_line(ig + ii, 1), 0, 0);
@@ -420,6 +433,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
         for (int ii = 0; ii < RG; ++ii)
 #pragma unroll
           for (int jp = 0; jp < 2; ++jp) {
+            if (ii >= cnt) continue;
             // inverse of the store shuffle (the swap is an involution)
             auto sa = __builtin_amdgcn_permlane16_swap(raw[ii][jp][0], raw[ii][jp][2], false, false);
             auto sb = __builtin_amdgcn_permlane16_swap(raw[ii][jp][1], raw[ii][jp][3], false, false);
@@ -432,12 +446,14 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
 #pragma unroll
           for (int jp = 0; jp < 2; ++jp)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) gpre[ii][jp][h] = __builtin_amdgcn_raw_buffer_load_b64(rsAux, off_elem(ig + ii, nn[jp][h], 2u), 0, 0);
+            for (int h = 0; h < 2; ++h)
+              if (ii < cnt) gpre[ii][jp][h] = __builtin_amdgcn_raw_buffer_load_b64(rsAux, off_elem(ig + ii, nn[jp][h], 2u), 0, 0);
       }
     }
 
 #pragma unroll
     for (int ii = 0; ii < RG; ++ii) {
+      if (ii >= cnt) continue;
       const int i = ig + ii;
       const long long m = m0 + wm * CFG::WROWS + i * 16 + (lane & 15);
       const bool okm = m < p.M;
