@@ -61,6 +61,17 @@ def main():
         assert fn() == 0, lib.vitssl_last_error()
         torch.cuda.synchronize()
         assert lib.vitssl_debug_attn_stamps(None) == 0
+        if name == "fwd" and N > 128 and os.environ.get("VITSSL_ATTN_FWD_PERSIST", "2") != "0":
+            # persistent forward: per workgroup, time of wave 0 per segment summed over its items
+            seg = stamps.cpu().numpy().reshape(-1, 8)[:256, :6].astype(np.float64)
+            seg = seg[seg[:, 5] > 0]
+            per = seg[:, :5] / seg[:, 5:6] / 100.0
+            labs = ("wait + barrier", "prefetch issue + S", "softmax", "P.V", "stores")
+            print(f"--- attn fwd (persistent): {len(seg)} workgroups x {seg[:, 5].mean():.1f} items; wave 0, us per item (median over workgroups):")
+            for i, lab in enumerate(labs):
+                print(f"    {lab:20s}: {np.median(per[:, i]):6.2f}")
+            print(f"    {'item':20s}: {np.median(per.sum(1)):6.2f}")
+            continue
         s = stamps.cpu().numpy().reshape(nwg, 4).astype(np.float64) / 100.0
         t0 = s[:, 0].min()
         d = np.diff(s, axis=1)

@@ -40,6 +40,14 @@ __device__ unsigned long long* g_attn_stamps = nullptr;   // [workgroup][4] x 10
   } while (0)
 #endif
 
+// 1: the fused backward's 8-wave form runs waves 4-7 one barrier behind waves 0-3 (two barriers per query step);
+// 0 (default): one barrier per step, all waves in phase.  Measured (B = 256, H = 12, N = 196, alternating runs): staggered
+// 276 us, in phase 242 us -- the second barrier per step costs more than the MFMA / VALU overlap between SIMD partners
+// returns; kept as an A/B build.  (Moving dV / dK behind the step's barrier, which both forms share, was worth 253 -> 242 us:
+// the dS columns are published before the 16 MFMAs + 32 transposed reads instead of after them.)
+#ifndef ATTN_BWD_STAGGER
+#define ATTN_BWD_STAGGER 0
+#endif
 // diagnostic builds only (tools/build_variant.sh): persistent forward without 1 = the arithmetic, 2 = the tile prefetch
 #ifndef ATTN_FWD_ABLATE
 #define ATTN_FWD_ABLATE 0
@@ -448,6 +456,24 @@ __global__ __launch_bounds__(1024 / QT, QT == 1 ? 4 : 2) void attn_fwd_pers_kern
   issue_tiles(item, smem, smem + TILE);
   load_q(item, qn);
   bool first = true;
+#ifdef VITSSL_ATTN_STAMPS
+  // diagnostic build: time (10 ns ticks) wave 0 spends in each segment, summed over the workgroup's items:
+  // 0 wait + barrier, 1 prefetch issue + S, 2 softmax, 3 P.V, 4 stores; 5 = items
+  unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = __builtin_amdgcn_s_memrealtime();
+#define PSTAMP(i)                                                   \
+  do {                                                              \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    const unsigned long long tn_ = __builtin_amdgcn_s_memrealtime(); \
+    seg[i] += tn_ - tprev;                                          \
+    tprev = tn_;                                                    \
+    __builtin_amdgcn_sched_barrier(0);                              \
+  } while (0)
+#else
+#define PSTAMP(i) \
+  do {            \
+  } while (0)
+#endif
 
   auto one_item = [&](auto cur_c) {
     constexpr int cur = decltype(cur_c)::value;
@@ -465,6 +491,7 @@ __global__ __launch_bounds__(1024 / QT, QT == 1 ? 4 : 2) void attn_fwd_pers_kern
     else __builtin_amdgcn_s_waitcnt(0x0F70 | (QT * 3));            // ... QT x (1 lse + 2 output rows halves)
     first = false;
     __builtin_amdgcn_s_barrier();
+    PSTAMP(0);
     bf16x8 qf[QT][2];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
@@ -486,9 +513,11 @@ __global__ __launch_bounds__(1024 / QT, QT == 1 ? 4 : 2) void attn_fwd_pers_kern
 #pragma unroll
         for (int t = 0; t < QT; ++t) sc[t][kt] = MFMA16(k1, qf[t][1], sc[t][kt]);
       }
+      PSTAMP(1);
       float m[QT], sum[QT], inv[QT];
 #pragma unroll
       for (int t = 0; t < QT; ++t) softmax_tile<NKT>(sc[t], m[t], sum[t]);
+      PSTAMP(2);
       __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)(lse + ((long long)b * H + h) * N), 0, N * 4, 0x00020000);
 #pragma unroll
       for (int t = 0; t < QT; ++t) {
@@ -544,6 +573,7 @@ __global__ __launch_bounds__(1024 / QT, QT == 1 ? 4 : 2) void attn_fwd_pers_kern
           for (int t = 0; t < QT; ++t) o[t][dt] = MFMA16(vf, pf[t], o[t][dt]);
         }
       });
+      PSTAMP(3);
       __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (long long)b * N * (H * DH)), 0, (int)out_bytes, 0x00020000);
 #pragma unroll
       for (int t = 0; t < QT; ++t) {
@@ -570,6 +600,10 @@ __global__ __launch_bounds__(1024 / QT, QT == 1 ? 4 : 2) void attn_fwd_pers_kern
           }
       }
     }
+    PSTAMP(4);
+#ifdef VITSSL_ATTN_STAMPS
+    seg[5] += 1;
+#endif
     item = next;
     return has_next;
   };
@@ -577,6 +611,11 @@ __global__ __launch_bounds__(1024 / QT, QT == 1 ? 4 : 2) void attn_fwd_pers_kern
     if (!one_item(IC2<0>{})) break;
     if (!one_item(IC2<1>{})) break;
   }
+#ifdef VITSSL_ATTN_STAMPS
+  if (g_attn_stamps && threadIdx.x == 0)
+    for (int i = 0; i < 6; ++i) g_attn_stamps[(size_t)blockIdx.x * 8 + i] = seg[i];
+#endif
+#undef PSTAMP
 }
 
 // ------------------------------------------------------------------ backward: dK, dV
@@ -954,16 +993,25 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(const bf16_t* _
     for (int tile = 0; tile < 8; tile += NW) dq_one(sx, qs, (wave + tile) >> 2, (wave + tile) & 3);
   };
 
-  // Software pipeline: the dQ tile of step qs-1 (independent MFMAs and LDS reads) is issued
-  // between the score MFMAs of step qs and their exp / dS arithmetic, so the matrix pipe has
-  // work while the VALU runs the softmax recompute.  One barrier per step: it publishes the
-  // dS columns of step qs and, because every wave's dQ reads of step qs-1 precede it in
-  // program order, also frees the other exchange buffer for step qs+1.
+  // Software pipeline: the dQ tile of step qs-1 (independent MFMAs and LDS reads) is issued between the score MFMAs of step
+  // qs and their exp / dS arithmetic, so the matrix pipe has work while the VALU runs the softmax recompute.
+  //
+  // A step is {scores + dQ(qs-1) + exp / dS / exchange writes} X {dV / dK}: the barrier X publishes the dS columns BEFORE the
+  // dV / dK products (round 3; they need nothing from other waves).
+  // ATTN_BWD_STAGGER = 1 (experiment, slower: see the macro): a second barrier Y per step, and waves 4-7 (the second wave of
+  // every SIMD) run ONE barrier behind waves 0-3, so that the VALU-heavy first half of one wave runs beside the MFMA /
+  // LDS-heavy second half of its SIMD partner.
+  // Events e0, e1, ...: waves 0-3 pass X(qs) = e(2qs), Y(qs) = e(2qs+1); waves 4-7 pass an extra barrier e0 first, then
+  // X(qs) = e(2qs+1), Y(qs) = e(2qs+2).  dS(qs) of every wave is published by e(2qs+1); dQ(qs-1) is read after e(2qs-1)
+  // (waves 0-3) / e(2qs) (waves 4-7): every writer is past its X(qs-1).  Buffer (qs+1)&1 is rewritten after e(2qs+1)
+  // / e(2qs+2): its last readers (dQ(qs-1)) finished before e(2qs) / e(2qs+1).  Waves 0-3 add one barrier after the loop.
+  const bool lag = ATTN_BWD_STAGGER && NW == 8 && wave >= 4;     // wave-uniform
+  if (lag) __syncthreads();
 #pragma unroll 1
   for (int qs = 0; qs < NS; ++qs) {
     char* sx = Sx + (qs & 1) * 32 * SROW;
+    f32x4 p[2][2], ds[2][2];  // [query tile in step][key tile]
     if (has_keys) {
-      f32x4 p[2][2], ds[2][2];  // [query tile in step][key tile]
       f32x4 a[2][2], c[2][2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -997,6 +1045,11 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(const bf16_t* _
             *(bf16_t*)(sx + (16 * t + 4 * g + r) * SROW + (32 * wave + 16 * kt + li) * 2) = f2bf(ds[t][kt][r]);
         }
       }
+    } else if (qs > 0) {
+      dq_tile(Sx + ((qs - 1) & 1) * 32 * SROW, qs - 1);
+    }
+    __syncthreads();   // X: this wave's dS columns of the step are in the image
+    if (has_keys) {
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
         const bf16x8 pf = pack_frag(p[0][kt], p[1][kt]);
@@ -1007,11 +1060,10 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(const bf16_t* _
           dk[dt][kt] = MFMA16(tr_frag(Qt, qs, dt, lane), sf, dk[dt][kt]);
         }
       }
-    } else if (qs > 0) {
-      dq_tile(Sx + ((qs - 1) & 1) * 32 * SROW, qs - 1);
     }
-    __syncthreads();   // every key owner's dS columns of this step are in the image
+    if (ATTN_BWD_STAGGER && NW == 8) __syncthreads();   // Y
   }
+  if (ATTN_BWD_STAGGER && NW == 8 && !lag) __syncthreads();     // waves 0-3: the event waves 4-7 pass as their last Y
   dq_tile(Sx + ((NS - 1) & 1) * 32 * SROW, NS - 1);
   ATTN_STAMP(2);
   if (has_keys) {
