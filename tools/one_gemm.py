@@ -13,10 +13,11 @@ torch.manual_seed(0)
 rb = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(torch.bfloat16)
 if kind == "nt":
     A, B = rb(M, K), rb(N, K)
+    B = (B.float() * (4.0 / K ** 0.5)).to(torch.bfloat16)      # outputs ~ N(0, 1), like a model's pre-activations
     out = torch.empty(M, N, dtype=torch.bfloat16 if epi in (0, 2, 4) else torch.float32, device=dev)
     out1 = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
     aux = torch.randn(M, N, device=dev) if epi == 3 else rb(M, N)
-    bias = torch.randn(N, device=dev)
+    bias = torch.randn(N, device=dev) * 0.1
     drop = ops.make_dropout(0.1, 1, 2) if (epi in (2, 3) and not os.environ.get("NODROP")) else ops.NO_DROP   # as in the model
     cs = torch.zeros(N, device=dev) if epi == 4 else None
     for _ in range(6):
