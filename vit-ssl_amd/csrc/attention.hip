@@ -1112,6 +1112,331 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(const bf16_t* _
 }
 
 
+// ------------------------------------------------------------------ backward, fused, pipelined prologue (N > 128)
+// attn_bwd_fused_kernel with the operand loads spread over the query sweep (round 3).  Stamps of the fused kernel (B = 256,
+// H = 12, N = 196): prologue 4.9 us of a 19.6 us workgroup -- all four tiles (Q, dO, K, O: 112 KB) land before the first MFMA,
+// although step qs of the sweep touches only rows 32 qs .. 32 qs + 31 of Q / dO (and, through delta, of O).  Here the
+// prologue waits for K, V and the first TWO 32-row slices; slice qs + 2 is requested by LDS-DMA at the top of step qs and is
+// covered by the wait + barrier that ends the step; delta = rowsum(dO * O) of slice qs + 1 is computed during step qs by the
+// last wave (which owns no keys at N <= 224) from a three-slot ring of O slices.
+// What that needs: nothing in the sweep may make hipcc drain the DMA queue -- the transposed reads are inline asm (for the
+// ds_read_tr builtin hipcc waits vmcnt(0) while an LDS-DMA is in flight), the step's barrier is a raw s_barrier behind a
+// BUILTIN s_waitcnt (vmcnt(0) of this wave's own, by then one step old, requests + lgkmcnt(0)), never __syncthreads().
+__device__ __forceinline__ void dma_rows8(__amdgpu_buffer_rsrc_t rs, char* lds_rows, int lrow0, long long stride, int grow0, int lane) {
+  const int rl = lane >> 3, c = lane & 7;
+  const int sc = c ^ ((((lrow0 + rl) >> 1) & 3) << 1);      // the tile's swizzle, by the row's position in its tile / ring slot
+  const unsigned voff = (unsigned)((long long)(grow0 + rl) * stride * 2 + sc * 16);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds_rows), 16, voff, 0, 0, 0);
+}
+template <int IMM>
+__device__ __forceinline__ void ds_tr16(s16x4& dst, unsigned addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(IMM));
+}
+__device__ __forceinline__ bf16x8 join_tr(const s16x4& lo, const s16x4& hi) {
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int NS>
+__global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ outp,
+                                                            const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                            bf16_t* __restrict__ dqkv, int N, int H, int stagger_wgs,
+                                                            int stagger_ticks, unsigned char* __restrict__ dq8,
+                                                            const float* __restrict__ qscale, float* qamax) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NW = 8;
+  constexpr int Np = 32 * NS;
+  constexpr int TILE = Np * ROWB;
+  constexpr int SROW = Np * 2 + 16;
+  const float qsc = (dq8 && qscale) ? *qscale : 1.0f;
+  float qmax = 0.f;
+  startup_stagger(stagger_wgs, stagger_ticks);
+  char* Qt = smem;
+  char* Dt = Qt + TILE;
+  char* Kt = Dt + TILE;
+  char* Sx = Kt + TILE;                 // 2 x [32][SROW]
+  float* lse_s = (float*)(Sx + 2 * 32 * SROW);
+  float* del_s = lse_s + Np;
+  char* Or = (char*)(del_s + Np);       // ring of three 32-row slices of O
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const long long stride = 3LL * H * DH, ostride = (long long)H * DH;
+  const bf16_t* qg = qkv + (long long)b * N * stride + h * DH;
+  const bf16_t* kg = qg + (long long)H * DH;
+  const bf16_t* vg = kg + (long long)H * DH;
+  const bf16_t* dog = dout + (long long)b * N * ostride + h * DH;
+  const bf16_t* og = outp + (long long)b * N * ostride + h * DH;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const bool has_keys = wave < NS;      // wave-uniform
+  const bool delta_wave = wave == NW - 1;
+
+  __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)qg, 0, (int)((long long)(N - 1) * stride * 2 + ROWB), 0x00020000);
+  __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)dog, 0, (int)((long long)(N - 1) * ostride * 2 + ROWB), 0x00020000);
+  __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)og, 0, (int)((long long)(N - 1) * ostride * 2 + ROWB), 0x00020000);
+  // the dQ rows of this (batch, head): [N, 3 H dh] bf16 (and its e4m3 image), row stride `stride`; only the q part is written here
+  __amdgpu_buffer_rsrc_t rsDQ = __builtin_amdgcn_make_buffer_rsrc((void*)(dqkv ? dqkv + (long long)b * N * stride : nullptr), 0,
+                                                                  dqkv ? (int)((long long)N * stride * 2) : 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsDQ8 = __builtin_amdgcn_make_buffer_rsrc((void*)(dq8 ? dq8 + (long long)b * N * stride : nullptr), 0,
+                                                                   dq8 ? (int)((long long)N * stride) : 0, 0x00020000);
+  const int dq_stores = (dqkv ? 1 : 0) + (dq8 ? 1 : 0);      // vector-memory stores of one dq_tile call (launch-uniform)
+  // slice s = rows 32 s .. 32 s + 31 of Q, dO (into their tiles) and O (into ring slot s % 3): 12 requests of 8 rows,
+  // waves 0-3: one of Q and one of O, waves 4-7: one of dO
+  auto issue_slice = [&](int s) {
+    const int j = wave & 3;
+    if (wave < 4) {
+      dma_rows8(rsQ, Qt + (32 * s + 8 * j) * ROWB, 32 * s + 8 * j, stride, 32 * s + 8 * j, lane);
+      dma_rows8(rsO, Or + ((s % 3) * 32 + 8 * j) * ROWB, 8 * j, ostride, 32 * s + 8 * j, lane);
+    } else {
+      dma_rows8(rsD, Dt + (32 * s + 8 * j) * ROWB, 32 * s + 8 * j, ostride, 32 * s + 8 * j, lane);
+    }
+  };
+  // delta (pre-multiplied by 1/sqrt(dh)) of slice s, by ONE wave: 2 lanes per row
+  auto delta_slice = [&](int s) {
+    const int rl = lane >> 1, half = lane & 1;
+    const int row = 32 * s + rl;
+    const char* orow = Or + (s % 3) * 32 * ROWB;
+    float part = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u32x4 ov = *(const u32x4*)(orow + tile_off(rl, half * 4 + j));
+      const u32x4 dv = *(const u32x4*)(Dt + tile_off(row, half * 4 + j));
+#pragma unroll
+      for (int w = 0; w < 4; ++w) part += bf_lo(ov[w]) * bf_lo(dv[w]) + bf_hi(ov[w]) * bf_hi(dv[w]);
+    }
+    part += __shfl_xor(part, 1, 64);
+    if (half == 0) del_s[row] = row < N ? part * SCALE : 0.f;
+  };
+
+  // ---- prologue: K tile, slices 0 and 1, V fragments, lse
+  ATTN_STAMP(0);
+  dma_tile<NW>(Kt, kg, stride, N, Np, wave, lane);
+  issue_slice(0);
+  if (NS > 1) issue_slice(1);
+  bf16x8 kf[2][2], vf[2][2];
+  f32x4 kinit[2];
+  if (has_keys) {
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      const int key = wave * 32 + kt * 16 + li;
+      const float mi = key < N ? 0.f : -INFINITY;
+      kinit[kt] = f32x4{mi, mi, mi, mi};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) vf[kt][kk] = glb_frag(vg, stride, key, kk, N, lane);
+    }
+  }
+  {
+    const int row = threadIdx.x >> 1;                 // 256 >= Np rows, two threads per row
+    const float l = row < N ? lse[((long long)b * H + h) * N + row] : 0.f;
+    if ((threadIdx.x & 1) == 0 && row < Np) lse_s[row] = row < N ? l * LOG2E : INFINITY;   // padded queries: p = exp2(x - inf) = 0
+  }
+  __builtin_amdgcn_s_waitcnt(0x0070);                 // vmcnt(0) lgkmcnt(0)
+  __syncthreads();
+  if (has_keys) {
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) kf[kt][kk] = lds_frag(Kt, wave * 32 + kt * 16 + li, kk, lane);
+  }
+  if (delta_wave) delta_slice(0);
+  __syncthreads();
+  ATTN_STAMP(1);
+
+  const f32x4 c4 = {SCALE_LOG2E, SCALE_LOG2E, SCALE_LOG2E, SCALE_LOG2E}, sc4 = {SCALE, SCALE, SCALE, SCALE};
+  f32x4 dv[4][2], dk[4][2];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      dv[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dk[dt][kt] = dv[dt][kt];
+    }
+  // transposed-read addresses (as tr_frag): tile base + row 4 g + q, chunk of column slice dt; + 4096 per 32-row step, + 2048
+  // for the second 16 rows, + TILE from the Q tile to the dO tile
+  const int tq = (lane >> 2) & 3, tpp = lane & 3;
+  const unsigned qbase = (unsigned)(size_t)LDS_PTR(Qt);
+  unsigned vrel[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) vrel[dt] = qbase + (unsigned)(tile_off(4 * g + tq, 2 * dt + (tpp >> 1)) + 8 * (tpp & 1));
+  const int dt_w = wave & 3, qt_w = wave >> 2;        // this wave's dQ tile of every step: (query tile, column slice)
+  const unsigned kaddr = vrel[0] - qbase + (unsigned)(size_t)LDS_PTR(Kt) +
+                         (unsigned)(tile_off(4 * g + tq, 2 * dt_w + (tpp >> 1)) - tile_off(4 * g + tq, (tpp >> 1)));
+
+  // dQ^T[d][q] = sum_key K[key][d] dS[q][key] for this wave's tile of step qs, from exchange image sx
+  auto dq_tile = [&](const char* sx, int qs) {
+    s16x4 klo[NS], khi[NS];
+    static_for<NS>([&](auto st_c) {
+      constexpr int st = decltype(st_c)::value;
+      ds_tr16<4096 * st>(klo[st], kaddr);
+      ds_tr16<4096 * st + 2048>(khi[st], kaddr);
+    });
+    const char* rowp = sx + (16 * qt_w + li) * SROW + 8 * g;
+    u32x2 dlo[NS], dhi[NS];
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      dlo[st] = *(const u32x2*)(rowp + 64 * st);        // keys 32st + 4g .. +3
+      dhi[st] = *(const u32x2*)(rowp + 64 * st + 32);   // keys 32st + 16 + 4g .. +3
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      const u32x4 w = {dlo[st][0], dlo[st][1], dhi[st][0], dhi[st][1]};
+      if (st & 1) acc1 = MFMA16(join_tr(klo[st], khi[st]), __builtin_bit_cast(bf16x8, w), acc1);
+      else acc0 = MFMA16(join_tr(klo[st], khi[st]), __builtin_bit_cast(bf16x8, w), acc0);
+    }
+    const f32x4 acc = acc0 + acc1;
+    const int q = qs * 32 + 16 * qt_w + li;
+    // unconditional stores through descriptors (rows >= N are out of range and dropped): every wave issues exactly one
+    // store per image and call, so the step's wait can be a counted one that leaves them in flight
+    const unsigned qoff = (unsigned)q * (unsigned)(stride * 2) + (unsigned)((h * DH + dt_w * 16 + 4 * g) * 2);
+    if (dqkv) __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3])}, rsDQ, qoff, 0, 0);
+    if (dq8) {
+      __builtin_amdgcn_raw_buffer_store_b32(pack_fp8x4(acc[0] * qsc, acc[1] * qsc, acc[2] * qsc, acc[3] * qsc), rsDQ8, qoff >> 1, 0, 0);
+      if (q < N) qmax = fmaxf(qmax, fmaxf(fmaxf(fabsf(acc[0]), fabsf(acc[1])), fmaxf(fabsf(acc[2]), fabsf(acc[3]))));
+    }
+  };
+
+#pragma unroll 1
+  for (int qs = 0; qs < NS; ++qs) {
+    char* sx = Sx + (qs & 1) * 32 * SROW;
+    if (qs + 2 < NS) issue_slice(qs + 2);
+    if (delta_wave && qs + 1 < NS) delta_slice(qs + 1);       // slice qs + 1 landed with the wait that ended step qs - 1
+    f32x4 p[2][2], ds[2][2];  // [query tile in step][key tile]
+    if (has_keys) {
+      f32x4 a[2][2], c[2][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int qrow = qs * 32 + t * 16 + li;
+        const bf16x8 qa0 = lds_frag(Qt, qrow, 0, lane), qa1 = lds_frag(Qt, qrow, 1, lane);
+        const bf16x8 da0 = lds_frag(Dt, qrow, 0, lane), da1 = lds_frag(Dt, qrow, 1, lane);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          a[t][kt] = kinit[kt];
+          c[t][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          a[t][kt] = MFMA16(qa0, kf[kt][0], a[t][kt]);
+          a[t][kt] = MFMA16(qa1, kf[kt][1], a[t][kt]);
+          c[t][kt] = MFMA16(da0, vf[kt][0], c[t][kt]);
+          c[t][kt] = MFMA16(da1, vf[kt][1], c[t][kt]);
+        }
+      }
+      if (qs > 0) dq_tile(Sx + ((qs - 1) & 1) * 32 * SROW, qs - 1);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const f32x4 nl = -*(const f32x4*)(lse_s + qs * 32 + t * 16 + 4 * g);
+        const f32x4 nd = -*(const f32x4*)(del_s + qs * 32 + t * 16 + 4 * g);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          const f32x4 e = __builtin_elementwise_fma(a[t][kt], c4, nl);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) p[t][kt][r] = __builtin_amdgcn_exp2f(e[r]);
+          ds[t][kt] = p[t][kt] * __builtin_elementwise_fma(c[t][kt], sc4, nd);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            *(bf16_t*)(sx + (16 * t + 4 * g + r) * SROW + (32 * wave + 16 * kt + li) * 2) = f2bf(ds[t][kt][r]);
+        }
+      }
+    } else if (qs > 0) {
+      dq_tile(Sx + ((qs - 1) & 1) * 32 * SROW, qs - 1);
+    }
+    // end of the step's first half: this wave's dS columns, its delta rows and its share of slice qs + 2 are complete.
+    // The dQ store(s) of this step were issued AFTER the slice's requests: they may stay in flight (counted vmcnt; a store
+    // acknowledgement is ~1 us away), lgkmcnt(0) covers the LDS writes.
+    if (qs == 0 || dq_stores == 0) __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0)
+    else if (dq_stores == 1) __builtin_amdgcn_s_waitcnt(0x0071);           // vmcnt(1)
+    else __builtin_amdgcn_s_waitcnt(0x0072);                               // vmcnt(2)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    if (has_keys) {
+      // dV^T += dO^T P, dK^T += Q^T dS: the transposed fragments of the step's 32 rows serve both key tiles
+      s16x4 qlo[4], qhi[4], dlo[4], dhi[4];
+      const unsigned soff = (unsigned)qs * 4096u;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        ds_tr16<TILE>(dlo[dt], vrel[dt] + soff);
+        ds_tr16<TILE + 2048>(dhi[dt], vrel[dt] + soff);
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        ds_tr16<0>(qlo[dt], vrel[dt] + soff);
+        ds_tr16<2048>(qhi[dt], vrel[dt] + soff);
+      }
+      bf16x8 pf[2], sf[2];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        pf[kt] = pack_frag(p[0][kt], p[1][kt]);
+        sf[kt] = pack_frag(ds[0][kt], ds[1][kt]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");      // the dO fragments are in; the Q fragments land under the dV MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x8 dfr = join_tr(dlo[dt], dhi[dt]);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) dv[dt][kt] = MFMA16(dfr, pf[kt], dv[dt][kt]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x8 qfr = join_tr(qlo[dt], qhi[dt]);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) dk[dt][kt] = MFMA16(qfr, sf[kt], dk[dt][kt]);
+      }
+    }
+  }
+  dq_tile(Sx + ((NS - 1) & 1) * 32 * SROW, NS - 1);
+  ATTN_STAMP(2);
+  if (has_keys) {
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      const int key = wave * 32 + kt * 16 + li;
+      if (dqkv) {
+        bf16_t* dkg = dqkv + ((long long)b * N + key) * stride + (long long)H * DH + h * DH;
+        bf16_t* dvg = dkg + (long long)H * DH;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) store_row_pair16_if(key < N, dkg, pr, g, pack4(dk[2 * pr][kt]), pack4(dk[2 * pr + 1][kt]));
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) store_row_pair16_if(key < N, dvg, pr, g, pack4(dv[2 * pr][kt]), pack4(dv[2 * pr + 1][kt]));
+      }
+      if (dq8) {
+        unsigned qk[4], qv[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const f32x4 a = dk[dt][kt], c = dv[dt][kt];
+          qk[dt] = pack_fp8x4(a[0] * qsc, a[1] * qsc, a[2] * qsc, a[3] * qsc);
+          qv[dt] = pack_fp8x4(c[0] * qsc, c[1] * qsc, c[2] * qsc, c[3] * qsc);
+          if (key < N) {
+            qmax = fmaxf(qmax, fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3]))));
+            qmax = fmaxf(qmax, fmaxf(fmaxf(fabsf(c[0]), fabsf(c[1])), fmaxf(fabsf(c[2]), fabsf(c[3]))));
+          }
+        }
+        const u32x4 rk = lane_rows_transpose4(qk), rv = lane_rows_transpose4(qv);
+        if (key < N) {
+          unsigned char* k8 = dq8 + ((long long)b * N + key) * stride + (long long)H * DH + h * DH + 16 * g;
+          *(u32x4*)k8 = rk;
+          *(u32x4*)(k8 + (long long)H * DH) = rv;
+        }
+      }
+    }
+  }
+  if (dq8 && qamax) {
+    qmax = wave_max(qmax);
+    unsigned* slot = (unsigned*)qamax;
+    if (lane == 0 && __float_as_uint(qmax) > __builtin_nontemporal_load(slot)) atomicMax(slot, __float_as_uint(qmax));
+  }
+#ifdef VITSSL_ATTN_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  ATTN_STAMP(3);
+}
+
+
 int attn_cu_count() {
   static int n = 0;
   if (!n) {
@@ -1200,9 +1525,31 @@ bool attn_bwd_split() {
   return v == 1;
 }
 
+// 1 (default): sequences of more than 128 tokens run the fused backward with the pipelined prologue; 0: attn_bwd_fused_kernel
+// (VITSSL_ATTN_BWD_PIPE, developer knob for A/B timing)
+bool attn_bwd_pipe() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("VITSSL_ATTN_BWD_PIPE");
+    v = e ? atoi(e) : 1;
+  }
+  return v != 0;
+}
+
 template <int NS>
 int launch_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, float* delta, bf16_t* dqkv, int B,
                int N, int H, hipStream_t s, unsigned char* dq8 = nullptr, const float* qscale = nullptr, float* qamax = nullptr) {
+  if constexpr (NS >= 5) {
+    if ((!attn_bwd_split() || dq8) && attn_bwd_pipe()) {
+      static bool done_p = false;
+      const int lds_p = 3 * NS * 32 * ROWB + 2 * 32 * (NS * 64 + 16) + 2 * NS * 32 * 4 + 3 * 32 * ROWB;
+      if (int rc = ensure_lds(attn_bwd_pipe_kernel<NS>, lds_p, &done_p, "attn_bwd_pipe")) return rc;
+      hipLaunchKernelGGL((attn_bwd_pipe_kernel<NS>), dim3(B * H), dim3(512), lds_p, s, qkv, out, dout, lse, dqkv, N, H,
+                         attn_cu_count(), B * H > 2 * attn_cu_count() ? attn_stagger_ticks(1) : 0, dq8, qscale, qamax);
+      VS_CHECK_LAUNCH("attn_bwd_pipe");
+      return VITSSL_OK;
+    }
+  }
   if (!attn_bwd_split() || dq8) {
     static bool done_f = false;
     constexpr int NW = NS <= 2 ? 2 : (NS <= 4 ? 4 : 8);
