@@ -117,7 +117,7 @@ typedef struct {
   const void* A;            /* bf16 [M,K] */
   const void* B;            /* bf16 [N,K] */
   int64_t M;
-  int N, K;                 /* K % 64 == 0, N % 4 == 0 */
+  int N, K;                 /* K % 64 == 0, N % 4 == 0 (fp8 operands: K % 128 == 0, N % 8 == 0) */
   int epilogue;
   const float* bias;        /* [N] or NULL */
   const void* aux;          /* epilogue-specific input or NULL */

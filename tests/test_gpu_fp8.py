@@ -205,7 +205,7 @@ def test_attention_bwd_fp8_image():
     assert rel_l2(_f32(d8) / 2.0 ** 13, d1) < 4e-2
 
 
-SHAPES = [(300, 128, 128), (1000, 384, 256), (517, 260, 1024), (4096, 512, 512)]
+SHAPES = [(300, 128, 128), (1000, 384, 256), (517, 264, 1024), (4096, 512, 512)]   # N % 8 == 0 (fp8 operands); ragged M, N
 
 
 @pytest.mark.parametrize("M,N,K", SHAPES)
@@ -251,6 +251,16 @@ def test_gemm_fp8_epilogues(M, N, K):
     assert torch.equal(a16, a16b)
 
 
+def test_gemm_fp8_refuses_n_not_multiple_of_8():
+    """fp8 operands run the ping-pong kernel only; its line-shaped stores move 8 columns per lane (include/vitssl_hip.h)."""
+    from vitssl_hip import _lib as L, ops
+    A = _q8_torch(torch.randn(64, 128)).to(DEV)
+    Bw = _q8_torch(torch.randn(260, 128)).to(DEV)
+    out = torch.empty(64, 260, device=DEV)
+    with pytest.raises(Exception, match="multiple of 8"):
+        ops.gemm_fp8_nt(A, Bw, out, L.EPI_F32)
+
+
 def test_gemm_fp8_identity_layout():
     """A = I against an asymmetric B: catches a row/column swap or a k-permutation that differs between operands."""
     from vitssl_hip import _lib as L, ops
@@ -265,7 +275,7 @@ def test_gemm_fp8_identity_layout():
     assert torch.equal(out.cpu(), Bm.t().contiguous())
 
 
-@pytest.mark.parametrize("M,N,K", [(600, 512, 256), (1000, 260, 128)])
+@pytest.mark.parametrize("M,N,K", [(600, 512, 256), (1000, 264, 128)])
 def test_gemm_fp8_dgelu_with_scaled_image(M, N, K):
     """The input-gradient form: dY (e4m3, scaled) . W^T image, dGELU epilogue, column sums, scaled e4m3 image + max|.|."""
     from vitssl_hip import _lib as L, ops

@@ -71,6 +71,13 @@
 #ifndef NT_RG_DGELU
 #define NT_RG_DGELU 2
 #endif
+// 1 (default): the ping-pong kernel's epilogue hands every 16-row tile of an output image through a private 2 KiB LDS window
+// of the wave, so that a store instruction's 64 lanes cover 8 rows x 128 CONTIGUOUS bytes with adjacent lanes on adjacent
+// addresses.  tools/probes/store_patterns.hip: a CU stores 55 GB/s in the accumulator layout (adjacent lanes = adjacent ROWS,
+// 16 bytes each: every lane is its own request) and 183-190 GB/s once four or more adjacent lanes are contiguous.
+#ifndef NT_LDS_T
+#define NT_LDS_T 1
+#endif
 // diagnostic builds only (tools/build_variant.sh): 1 = epilogue arithmetic and loads but NO stores,
 // 2 = stores but no GELU / dropout arithmetic and no residual / g' loads
 #ifndef NT_ABLATE
@@ -209,10 +216,16 @@ __device__ __forceinline__ unsigned glut_read(const char* smem, unsigned a) {
 }
 
 // Fused epilogue of one 128x64 wave tile (shared by both main-loop variants).
-template <int EPI, typename CFG, bool Q8 = false, int GLUT_OFF = -1>
+template <int EPI, typename CFG, bool Q8 = false, int GLUT_OFF = -1, bool TLS = false>
 __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][CFG::MI], const long long m0, const int n0,
-                                            const int wm, const int wn, const int lane, const char* lds = nullptr) {
+                                            const int wm, const int wn, const int lane_in, const char* lds = nullptr, char* xs = nullptr) {
   constexpr int MI = CFG::MI;
+  // the lane-only address constants below are re-derived in every epilogue: hoisted out of the tile loop they stay live through
+  // the K loop, and the 256-row kernels (128 accumulator registers) then spill K-loop state into scratch
+  int lane = lane_in;
+  if (TLS) asm volatile("" : "+v"(lane));
+  // TLS: xs = this wave's private 2 KiB of LDS (ping-pong kernel: its own B1 staging slots of the buffer that is not being
+  // refilled, see the kernel) and N is a multiple of 8; otherwise the stores leave in the accumulator layout
   // GLUT_OFF >= 0: LDS byte offset of the GELU table minus GLUT_LO8 (the ds_read's immediate)
   constexpr bool GLUT = EPI == VITSSL_EPI_GELU && GLUT_OFF >= 0 && NT_ABLATE == 0;
   // fp8 operands: the table's entries are (bf16 s gelu'(u)) | (e4m3(s gelu(u) qs) << 16) -- the e4m3 byte is quantised from
@@ -238,7 +251,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
   const int g4 = lane >> 4;                       // lane group = 16-lane row of the wave
   // bf16 images: tile columns (j, j+1) exchange halves between lane rows (g, g^1) with
   // v_permlane16_swap so that every lane moves 16 contiguous bytes (8 columns).
-  const bool wide = (p.N & 7) == 0;
+  const bool wide = TLS || (p.N & 7) == 0;
   constexpr unsigned OOB = 0x80000000u;
   const long long rows_left = p.M - m0;
   auto window = [&](const void* base, int elt) {
@@ -293,6 +306,29 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
     auto hi = __builtin_amdgcn_permlane16_swap(w0[1], w1[1], false, false);
     return u32x4{lo[0], hi[0], lo[1], hi[1]};
   };
+  // ---- line-shaped stores through the wave's LDS window (NT_LDS_T).  A 16-row tile of an image is 16 rows x 128 bytes
+  // (64 bf16 columns, or the 32 fp32 columns of a pair).  It is written in the accumulator layout (lane (m, c) = row m, 8- or
+  // 16-byte chunk), with the chunk position XORed by the row so the writes spread over the banks, and read back as lane
+  // (rho, kappa) = row rho (+8 for the second read), 16-byte chunk kappa: 8 lanes = one 128-byte line.
+  constexpr bool tls = TLS;
+  const int tm = lane & 15, trho = lane >> 3, tkap = lane & 7;
+  // bf16: this lane's 8-byte chunk of tile j is chunk (4j + c) ^ 2 (m >> 1) of row m: tile 0's offset, tile j's = that ^ 32 j
+  const unsigned tw16 = (unsigned)(tm * 128 + ((g4 ^ (2 * (tm >> 1))) << 3));
+  const unsigned tr16a = (unsigned)(trho * 128 + ((tkap ^ (trho >> 1)) << 4));      // rows 0-7: 16-byte chunk kappa; rows 8-15: (+1024) ^ 64
+  // fp32: 16-byte chunk (4h + c) ^ (m & 7) of the pair's 128-byte row: tile 0's offset, tile 1's = that ^ 64
+  const unsigned tw32 = (unsigned)(tm * 128 + ((g4 ^ (tm & 7)) << 4));
+  const unsigned tr32a = (unsigned)(trho * 128 + ((tkap ^ trho) << 4));              // rows 8-15: + 1024 ((rho + 8) & 7 == rho & 7)
+  const unsigned trow = (unsigned)(wm * CFG::WROWS + trho);                // + 16 i (+ 8): row inside the tile
+  // lane part of the offsets (row trho of tile 0; out-of-range columns get the sentinel, which stays out of range when the
+  // wave-uniform row term below is added: that term is < 2^31); the row term is scalar arithmetic
+  const int tn16 = n0 + wn * 64 + 8 * tkap;
+  const unsigned tb16 = tn16 < p.N ? (trow * un + (unsigned)tn16) * 2u : OOB;
+  auto off_line16 = [&](int i, int half) -> unsigned { return tb16 + (unsigned)(16 * i + 8 * half) * (un * 2u); };   // bf16 image: 8 columns per lane
+  auto off_line32 = [&](int i, int jp, int half) -> unsigned {              // fp32 image: 4 columns per lane
+    const int n = n0 + wn * 64 + 32 * jp + 4 * tkap;
+    const unsigned b = n < p.N ? (trow * un + (unsigned)n) * 4u : OOB;
+    return b + (unsigned)(16 * i + 8 * half) * (un * 4u);
+  };
   // one row tile of a bf16 image: w[jp][h]
   constexpr int BF16_AUX = NT_STORE_AUX != 0 ? NT_STORE_AUX : NT_BF16_AUX;
   auto store_bf16_row = [&](__amdgpu_buffer_rsrc_t rs, int i, const u32x2 (&w)[2][2], auto aux_c) {
@@ -301,7 +337,15 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
       asm volatile("" ::"v"(w[0][0]), "v"(w[0][1]), "v"(w[1][0]), "v"(w[1][1]));
       return;
     }
-    if (wide) {
+    if (tls) {
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) *(u32x2*)(xs + (tw16 ^ (unsigned)(32 * (2 * jp + h)))) = w[jp][h];
+      const u32x4 s1 = *(const u32x4*)(xs + tr16a), s2 = *(const u32x4*)(xs + ((tr16a + 1024u) ^ 64u));
+      __builtin_amdgcn_raw_buffer_store_b128(s1, rs, off_line16(i, 0), 0, AUXV);
+      __builtin_amdgcn_raw_buffer_store_b128(s2, rs, off_line16(i, 1), 0, AUXV);
+    } else if (wide) {
       const u32x4 a = pack_pair(w[0][0], w[0][1]), b = pack_pair(w[1][0], w[1][1]);
       if (NT_ROWS128) {
         u32x4 s1, s2;
@@ -328,7 +372,13 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
       asm volatile("" ::"v"(v0), "v"(v1));
       return;
     }
-    if (NT_ROWS128) {
+    if (tls) {
+      *(f32x4*)(xs + tw32) = v0;
+      *(f32x4*)(xs + (tw32 ^ 64u)) = v1;
+      const u32x4 s1 = *(const u32x4*)(xs + tr32a), s2 = *(const u32x4*)(xs + tr32a + 1024);
+      __builtin_amdgcn_raw_buffer_store_b128(s1, rs, off_line32(i, jp, 0), 0, F32_AUX);
+      __builtin_amdgcn_raw_buffer_store_b128(s2, rs, off_line32(i, jp, 1), 0, F32_AUX);
+    } else if (NT_ROWS128) {
       u32x4 s1, s2;
       to_lines(__builtin_bit_cast(u32x4, v0), __builtin_bit_cast(u32x4, v1), s1, s2);
       __builtin_amdgcn_raw_buffer_store_b128(s1, rs, off_f32_line(i, jp, 0), 0, F32_AUX);
@@ -400,6 +450,10 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
           if (ii >= cnt) continue;
           if (NT_ABLATE == 2) {
             res[ii][jp][0] = res[ii][jp][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+          } else if (tls) {
+            // whole lines (8 rows x 128 bytes per instruction); turned into the accumulator layout through the LDS window at use
+            res[ii][jp][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_line32(ig + ii, jp, 0), 0, 0));
+            res[ii][jp][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_line32(ig + ii, jp, 1), 0, 0));
           } else if (NT_ROWS128) {
             const u32x4 l1 = __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_f32_line(ig + ii, jp, 0), 0, 0);
             const u32x4 l2 = __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_f32_line(ig + ii, jp, 1), 0, 0);
@@ -420,7 +474,10 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
 #pragma unroll
         for (int ii = 0; ii < RG; ++ii) {
           if (ii >= cnt) continue;
-          if (NT_ROWS128) {
+          if (tls) {
+            raw[ii][0] = __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_line16(ig + ii, 0), 0, 0);    // rows 0-7 of the row tile, whole lines
+            raw[ii][1] = __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_line16(ig + ii, 1), 0, 0);    // rows 8-15
+          } else if (NT_ROWS128) {
             const u32x4 l1 = __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_bf16_line(ig + ii, 0), 0, 0);
             const u32x4 l2 = __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_bf16_line(ig + ii, 1), 0, 0);
             from_lines(l1, l2, raw[ii][0], raw[ii][1]);
@@ -434,6 +491,15 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
 #pragma unroll
           for (int jp = 0; jp < 2; ++jp) {
             if (ii >= cnt) continue;
+            if (tls) {
+              if (jp == 0) {                        // (both pairs at once: the window holds the whole row tile)
+                *(u32x4*)(xs + tr16a) = raw[ii][0];
+                *(u32x4*)(xs + ((tr16a + 1024u) ^ 64u)) = raw[ii][1];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gpre[ii][j >> 1][j & 1] = *(const u32x2*)(xs + (tw16 ^ (unsigned)(32 * j)));
+              }
+              continue;
+            }
             // inverse of the store shuffle (the swap is an involution)
             auto sa = __builtin_amdgcn_permlane16_swap(raw[ii][jp][0], raw[ii][jp][2], false, false);
             auto sb = __builtin_amdgcn_permlane16_swap(raw[ii][jp][1], raw[ii][jp][3], false, false);
@@ -570,6 +636,12 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
         } else if constexpr (EPI == VITSSL_EPI_F32) {
           store_f32_pair(rsOut0, i, jp, v[0], v[1], nn[jp]);
         } else if constexpr (EPI == VITSSL_EPI_RESID) {
+          if (tls && NT_ABLATE != 2) {            // the pair's residual lines -> accumulator layout (inverse of store_f32_pair's path)
+            *(f32x4*)(xs + tr32a) = res[ii][jp][0];
+            *(f32x4*)(xs + tr32a + 1024) = res[ii][jp][1];
+            res[ii][jp][0] = *(const f32x4*)(xs + tw32);
+            res[ii][jp][1] = *(const f32x4*)(xs + (tw32 ^ 64u));
+          }
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             if (p.drop_on && NT_ABLATE != 2) {
@@ -1197,7 +1269,10 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_nt_pp_kernel(NtParams p)
           for (int i = 0; i < MI; ++i) acc[j][i] *= al;
       }
     }
-    nt_epilogue<EPI, CFG, F8, GLUT_IMM>(p, acc, m0, n0, wm, wn, lane, smem);
+    // the wave's LDS window for line-shaped stores: its own two B1 staging slots (2 KiB, contiguous) of the buffer whose B1 / A1
+    // units are not in flight -- K-tile (last) read them two barriers ago, and this wave itself re-issues them in p0 of the
+    // next K-tile, after its epilogue in program order; no other wave ever writes there
+    nt_epilogue<EPI, CFG, F8, GLUT_IMM, NT_LDS_T != 0 && NT_ROWS128 == 0>(p, acc, m0, n0, wm, wn, lane, smem, smem + (buf ^ 1) * BUF + ldsB[1][0]);
     stamp(round, 2);
 #ifdef VITSSL_NT_STAMPS
     if (p.stamps) {                                    // diagnostic: when have this wave's stores been acknowledged?
@@ -1285,6 +1360,10 @@ int launch_cfg(NtParams p, hipStream_t s) {
   else if (p.tiles_n % 3 == 0) p.group_n = 3;
   else p.group_n = want < 4 ? want : 4;
   if (p.esz == 1) {
+    if ((p.N & 7) != 0) {
+      vitssl_set_error("gemm_fp8_nt: N=%d must be a multiple of 8", p.N);
+      return VITSSL_ERR_ARG;
+    }
     // fp8 operands exist for the ping-pong loop and the epilogues of the transformer-block forward only
     if constexpr (CFG::WAVES == 8 && CFG::BK == 64 &&
                   (EPI == VITSSL_EPI_BF16 || EPI == VITSSL_EPI_F32 || EPI == VITSSL_EPI_GELU || EPI == VITSSL_EPI_RESID ||
@@ -1296,7 +1375,7 @@ int launch_cfg(NtParams p, hipStream_t s) {
     }
   }
   if constexpr (CFG::WAVES == 8 && CFG::BK == 64 && EPI != EPI_F32_SPLITK) {
-    if (nt_pp_enabled() && p.k_chunk == 0) return launch_pp<EPI, CFG>(p, s);
+    if (nt_pp_enabled() && p.k_chunk == 0 && (p.N & 7) == 0) return launch_pp<EPI, CFG>(p, s);   // (its line-shaped stores move 8 columns per lane)
   }
   // Persistent workgroups.  Measured on MI355X (bench.py, same box, alternating runs): with
   // K = 768 / 3072 (ViT-B) the NT family takes 23.12 ms per step either way and the whole step
