@@ -201,12 +201,30 @@ constexpr int GLUT_BYTES = GLUT_ENTRIES * 4;
 constexpr unsigned GLUT_LO8 = (unsigned)GLUT_E_LO << 10;  // magnitude part of the byte address: (h & 0x7fff) << 3
 constexpr unsigned GLUT_HI8 = (unsigned)(GLUT_E_LO + GLUT_BINADES) << 10;
 
-// byte address (relative to table base - GLUT_LO8) of the entries of the two bf16 halves of w
-__device__ __forceinline__ void glut_addr2(unsigned w, unsigned& mag0, unsigned& sgn0, unsigned& mag1, unsigned& sgn1) {
-  mag0 = (w << 3) & 0x3fff8u;
-  sgn0 = (w >> 13) & 4u;
-  mag1 = (w >> 13) & 0x3fff8u;
-  sgn1 = (w >> 29) & 4u;
+// Table addressing.  Entry (magnitude index m, sign s) of bf16 pattern h sits at byte (2 m + s) * 4 = rot16(h, 1) * 4 (relative to
+// table base - GLUT_LO8): both halves of a packed pair are rotated by two packed 16-bit instructions, an SDWA shift per element
+// turns a half into its byte address, and the range test of a 4-element group is three packed 16-bit instructions on the
+// rotated words (16 instructions per group less than shift / and / min / or per element).  A lane outside the table's range
+// reads staging bytes or beyond the workgroup's LDS (reads return 0 there): its group is redone arithmetically.
+__device__ __forceinline__ unsigned glut_rot2(unsigned w) {
+  unsigned t, r;
+  asm("v_pk_lshrrev_b16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(t) : "v"(w));            // sign of each half (the inline constant serves both)
+  asm("v_pk_mad_u16 %0, %1, 2, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(w), "v"(t));     // (h << 1) + sign, modulo 2^16
+  return r;
+}
+__device__ __forceinline__ void glut_addr2(unsigned r, unsigned& a0, unsigned& a1) {
+  asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(a0) : "v"(r));
+  asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(a1) : "v"(r));
+}
+// true when any of the four rotated patterns lies outside [2 LO, 2 HI): d = r - 2 LO (modulo 2^16) must be <= 2 (HI - LO) - 1
+__device__ __forceinline__ bool glut_out_of_range(unsigned r01, unsigned r23) {
+  const unsigned lo2 = ((unsigned)GLUT_E_LO << 8) * 0x10001u, span = ((unsigned)(GLUT_BINADES << 8) - 1u) * 0x10001u;
+  unsigned d01, d23, dm, e;
+  asm("v_pk_sub_u16 %0, %1, %2" : "=v"(d01) : "v"(r01), "s"(lo2));
+  asm("v_pk_sub_u16 %0, %1, %2" : "=v"(d23) : "v"(r23), "s"(lo2));
+  asm("v_pk_max_u16 %0, %1, %2" : "=v"(dm) : "v"(d01), "v"(d23));
+  asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(e) : "v"(dm), "s"(span));
+  return e != 0;
 }
 // plain LDS loads (the compiler counts them): checked in the .s that no vmcnt wait is attached to them -- the operand DMA in
 // flight during the epilogue writes other LDS bytes, but hipcc cannot always prove that (cdna guide, "three .s-level traps")
@@ -535,15 +553,14 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
           for (int h = 0; h < 2; ++h) {
             const f32x4 vv = acc[2 * jp + h][i] + bias4[jp][h];
             const unsigned w0 = pack_bf2(vv[0], vv[1]), w1 = pack_bf2(vv[2], vv[3]);
-            unsigned mg[4], sg[4];
-            glut_addr2(w0, mg[0], sg[0], mg[1], sg[1]);
-            glut_addr2(w1, mg[2], sg[2], mg[3], sg[3]);
-            const unsigned mn = min(min(mg[0], mg[1]), min(mg[2], mg[3])), mx = max(max(mg[0], mg[1]), max(mg[2], mg[3]));
-            gslow[jp][h] = __builtin_amdgcn_ballot_w64(mn < GLUT_LO8 || mx >= GLUT_HI8) != 0;
-            // (a lane above the range is clamped onto the last entry, one below it reads staging bytes: both are discarded)
+            const unsigned r01 = glut_rot2(w0), r23 = glut_rot2(w1);
+            gslow[jp][h] = __builtin_amdgcn_ballot_w64(glut_out_of_range(r01, r23)) != 0;
+            unsigned ad[4];
+            glut_addr2(r01, ad[0], ad[1]);
+            glut_addr2(r23, ad[2], ad[3]);
             const int q = 8 * jp + 4 * h;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gl[q + r] = glut_read<GLUT_OFF>(lds, min(mg[r], GLUT_HI8 - 8u) | sg[r]);
+            for (int r = 0; r < 4; ++r) gl[q + r] = glut_read<GLUT_OFF>(lds, ad[r]);
           }
       }
 #pragma unroll
@@ -694,8 +711,19 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
             auto s13 = __builtin_amdgcn_permlane32_swap(out_q[0][1], out_q[1][1], false, false);
             auto e = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
             auto f = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
-            const int n = n0 + wn * 64 + 16 * g4;
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{e[0], e[1], f[0], f[1]}, rsOut2, off_elem(i, n, 1u), 0, BF16_AUX);
+            if (tls) {
+              // 16 rows x 64 bytes through the LDS window: written as lane (m, c) -> row m, chunk c ^ ((m >> 1) & 3), read as
+              // lane (rho = lane >> 2, kappa = lane & 3): the four lanes of a quad cover one row's 64 contiguous bytes
+              *(u32x4*)(xs + tm * 64 + ((g4 ^ ((tm >> 1) & 3)) << 4)) = u32x4{e[0], e[1], f[0], f[1]};
+              const int rho4 = lane >> 2, kap4 = lane & 3;
+              const u32x4 s8 = *(const u32x4*)(xs + rho4 * 64 + ((kap4 ^ ((rho4 >> 1) & 3)) << 4));
+              const int n8 = n0 + wn * 64 + 16 * kap4;
+              const unsigned o8 = n8 < p.N ? ((unsigned)(wm * CFG::WROWS + 16 * i + rho4) * un + (unsigned)n8) : OOB;
+              __builtin_amdgcn_raw_buffer_store_b128(s8, rsOut2, o8, 0, BF16_AUX);
+            } else {
+              const int n = n0 + wn * 64 + 16 * g4;
+              __builtin_amdgcn_raw_buffer_store_b128(u32x4{e[0], e[1], f[0], f[1]}, rsOut2, off_elem(i, n, 1u), 0, BF16_AUX);
+            }
           } else {
 #pragma unroll
             for (int jp = 0; jp < 2; ++jp)
