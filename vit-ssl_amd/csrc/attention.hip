@@ -575,18 +575,20 @@ __global__ __launch_bounds__(1024 / QT, QT == 1 ? 4 : 2) void attn_fwd_pers_kern
       });
       PSTAMP(3);
       __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (long long)b * N * (H * DH)), 0, (int)out_bytes, 0x00020000);
+      // line-shaped stores (csrc/gemm_nt.hip, NT_LDS_T): the tile's 16 rows x 128 bytes pass through the wave's private 2 KiB LDS
+      // window behind the four K / V tiles and leave as two instructions of 8 rows x 128 contiguous bytes (same count as before)
+      char* xw = smem + 4 * TILE + wave * 2048;
+      const int rho = lane >> 3, kap = lane & 7;
+      const unsigned tw = (unsigned)(li * 128 + ((g ^ (2 * (li >> 1))) << 3));
+      const unsigned tr = (unsigned)(rho * 128 + ((kap ^ (rho >> 1)) << 4));
 #pragma unroll
       for (int t = 0; t < QT; ++t) {
-        const unsigned rowoff = (unsigned)q[t] * (unsigned)(H * DH * 2) + (unsigned)(h * DH * 2);    // beyond out_bytes for q >= N
 #pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-          const u32x2 w0 = pack4(o[t][2 * pr] * inv[t]), w1 = pack4(o[t][2 * pr + 1] * inv[t]);
-          auto lo2 = __builtin_amdgcn_permlane16_swap(w0[0], w1[0], false, false);
-          auto hi2 = __builtin_amdgcn_permlane16_swap(w0[1], w1[1], false, false);
-          const int odd = g & 1;
-          __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo2[0], hi2[0], lo2[1], hi2[1]}, ro,
-                                                 rowoff + (unsigned)(((2 * pr + odd) * 16 + 4 * (g - odd)) * 2), 0, 0);
-        }
+        for (int dt = 0; dt < 4; ++dt) *(u32x2*)(xw + (tw ^ (unsigned)(32 * dt))) = pack4(o[t][dt] * inv[t]);
+        const u32x4 s1 = *(const u32x4*)(xw + tr), s2 = *(const u32x4*)(xw + ((tr + 1024u) ^ 64u));
+        const unsigned rowoff = (unsigned)((wave * QT + t) * 16 + rho) * (unsigned)(H * DH * 2) + (unsigned)(h * DH * 2 + 16 * kap);   // beyond out_bytes for rows >= N
+        __builtin_amdgcn_raw_buffer_store_b128(s1, ro, rowoff, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(s2, ro, rowoff + 8u * (unsigned)(H * DH * 2), 0, 0);
       }
       if (out8) {
         __amdgpu_buffer_rsrc_t r8 = __builtin_amdgcn_make_buffer_rsrc((void*)(out8 + (long long)b * N * (H * DH)), 0, (int)(out_bytes / 2), 0x00020000);
@@ -1397,12 +1399,24 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(const bf16_t* __rest
     for (int kt = 0; kt < 2; ++kt) {
       const int key = wave * 32 + kt * 16 + li;
       if (dqkv) {
-        bf16_t* dkg = dqkv + ((long long)b * N + key) * stride + (long long)H * DH + h * DH;
-        bf16_t* dvg = dkg + (long long)H * DH;
+        // Line-shaped stores (as the NT GEMM epilogue, csrc/gemm_nt.hip NT_LDS_T): the 16 x 128-byte tile goes through a private
+        // 2 KiB LDS window and leaves as 8 rows x 128 contiguous bytes per instruction.  The window is rows 16 w .. 16 w + 15 of
+        // the Q tile: slices <= NS - 2 (rows < 32 (NS - 1), NS >= 5) were last read before the final step's barrier.
+        char* xw = Qt + wave * 2048;
+        const int rho = lane >> 3, kap = lane & 7;
+        const unsigned tw = (unsigned)(li * 128 + ((g ^ (2 * (li >> 1))) << 3));
+        const unsigned tr = (unsigned)(rho * 128 + ((kap ^ (rho >> 1)) << 4));
+        const int key_a = wave * 32 + kt * 16 + rho;
+        bf16_t* dka = dqkv + ((long long)b * N + key_a) * stride + (long long)H * DH + h * DH + 8 * kap;
 #pragma unroll
-        for (int pr = 0; pr < 2; ++pr) store_row_pair16_if(key < N, dkg, pr, g, pack4(dk[2 * pr][kt]), pack4(dk[2 * pr + 1][kt]));
+        for (int tsel = 0; tsel < 2; ++tsel) {        // dK, then dV
 #pragma unroll
-        for (int pr = 0; pr < 2; ++pr) store_row_pair16_if(key < N, dvg, pr, g, pack4(dv[2 * pr][kt]), pack4(dv[2 * pr + 1][kt]));
+          for (int dt = 0; dt < 4; ++dt) *(u32x2*)(xw + (tw ^ (unsigned)(32 * dt))) = pack4(tsel == 0 ? dk[dt][kt] : dv[dt][kt]);
+          const u32x4 s1 = *(const u32x4*)(xw + tr), s2 = *(const u32x4*)(xw + ((tr + 1024u) ^ 64u));
+          bf16_t* dst = dka + (long long)tsel * H * DH;
+          if (key_a < N) *(u32x4*)dst = s1;
+          if (key_a + 8 < N) *(u32x4*)(dst + 8 * stride) = s2;
+        }
       }
       if (dq8) {
         unsigned qk[4], qv[4];
@@ -1490,7 +1504,7 @@ int launch_fwd(const bf16_t* qkv, bf16_t* out, float* lse, float* probs, int B, 
   if constexpr (NS >= 5) {
     if (attn_fwd_persist()) {
       static bool done_p1 = false, done_p2 = false;
-      const int lds_p = 4 * NS * 32 * ROWB;            // two (K, V) tile pairs
+      const int lds_p = 4 * NS * 32 * ROWB + 16 * 2048;   // two (K, V) tile pairs + a 2 KiB output window per wave (16 waves at most)
       const int nitems = B * H;
       const int grid = nitems < attn_cu_count() ? nitems : attn_cu_count();
       if (attn_fwd_persist() == 2) {                   // 8 waves x two query tiles

@@ -78,6 +78,10 @@
 #ifndef NT_LDS_T
 #define NT_LDS_T 1
 #endif
+// start-up stagger window of the ping-pong kernel in tile times (VITSSL_NT_STAGGER overrides)
+#ifndef NT_STAGGER_DEFAULT
+#define NT_STAGGER_DEFAULT 1.0f
+#endif
 // diagnostic builds only (tools/build_variant.sh): 1 = epilogue arithmetic and loads but NO stores,
 // 2 = stores but no GELU / dropout arithmetic and no residual / g' loads
 #ifndef NT_ABLATE
@@ -1346,9 +1350,11 @@ int launch_pp(NtParams p, hipStream_t s) {
   static float stagger_scale = -1.f;
   if (stagger_scale < 0.f) {
     const char* e = getenv("VITSSL_NT_STAGGER");       // developer knob: scale of the window, 0 = off
-    // default OFF: time-neutral (the epilogue is bound inside each CU, not by a chip-wide burst) and it costs L2
-    // sharing -- workgroups on the same A row panel no longer run in step, FETCH_SIZE of the N = 768 launches x2
-    stagger_scale = e ? (float)atof(e) : 0.0f;
+    // Round 2 measured this time-neutral: in the accumulator layout a CU's stores were bound inside the CU (55 GB/s) whether or not
+    // the other CUs stored at the same moment.  With line-shaped epilogue accesses (NT_LDS_T) a CU alone stores 180+ GB/s but only
+    // ~55 when all 256 burst together, so spreading the epilogues now pays: interleaved A/B, M = 50176: dGELU 281 -> 262 us
+    // (N = 3072, K = 768), residual 241 -> 231 (K = 3072), plain stores -1.5..-3 %, never slower; whole step 34.29 -> 34.05 ms.
+    stagger_scale = e ? (float)atof(e) : NT_STAGGER_DEFAULT;
   }
   const float epi_us = EPI == VITSSL_EPI_BF16 ? 2.f : EPI == VITSSL_EPI_GELU ? 7.f : EPI == VITSSL_EPI_DGELU ? 5.f
                        : EPI == VITSSL_EPI_RESID ? 8.f : 4.f;
