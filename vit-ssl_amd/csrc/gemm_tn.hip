@@ -170,7 +170,7 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(TnParams p) {
 // (a half is refilled two phases after its last fragment read: Bk0 is read in p0, Ak0 in p0-p1, Bk1 in
 // p2, Ak1 in p2-p3; the wait covering a half sits in the phase before its first read).
 typedef __attribute__((ext_vector_type(8))) short tn_s16x8;
-// diagnostic builds only (tools/build_variant.sh): 1 = no DMA inside the K loop, 2 = no fragment reads, 3 = no MFMA
+// diagnostic builds only (tools/build_variant.sh), bit mask: 1 = no DMA inside the K loop, 2 = no fragment reads, 4 = no MFMA
 #ifndef TN_ABLATE
 #define TN_ABLATE 0
 #endif
@@ -253,14 +253,14 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_pp_kernel(TnParams p) {
   auto stage_a = [&](int t, int bufsel, auto h_c) {
     constexpr int h = decltype(h_c)::value;
     const unsigned b = baseA(t);
-    if (TN_ABLATE == 1 && t >= 2) return;
+    if ((TN_ABLATE & 1) && t >= 2) return;
 #pragma unroll
     for (int e = 0; e < 2; ++e) tn_dma16(rsA, smem + bufsel * BUF + ldsA[h][e], voffA[h][e] + b);
   };
   auto stage_b = [&](int t, int bufsel, auto h_c) {
     constexpr int h = decltype(h_c)::value;
     const unsigned b = baseB(t);
-    if (TN_ABLATE == 1 && t >= 2) return;
+    if ((TN_ABLATE & 1) && t >= 2) return;
 #pragma unroll
     for (int e = 0; e < 2; ++e) tn_dma16(rsB, smem + bufsel * BUF + ldsB[h][e], voffB[h][e] + b);
   };
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_pp_kernel(TnParams p) {
   bf16x8 fa[4], fb[4];
   auto read_b = [&](int bufoff, auto ks_c) {
     constexpr int ks = decltype(ks_c)::value;
-    if (TN_ABLATE == 2 && bufoff >= 0) return;
+    if ((TN_ABLATE & 2) && bufoff >= 0) return;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const unsigned a = fragB[j] + (unsigned)bufoff;
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_pp_kernel(TnParams p) {
   };
   auto read_a = [&](int bufoff, auto ks_c, auto ih_c) {
     constexpr int ks = decltype(ks_c)::value, ih = decltype(ih_c)::value;
-    if (TN_ABLATE == 2 && bufoff >= 0) return;
+    if ((TN_ABLATE & 2) && bufoff >= 0) return;
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii) {
       const unsigned a = fragA[4 * ih + ii] + (unsigned)bufoff;
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_pp_kernel(TnParams p) {
   };
   auto mma = [&](auto ih_c) {
     constexpr int ih = decltype(ih_c)::value;
-    if (TN_ABLATE == 3) {
+    if (TN_ABLATE & 4) {
       asm volatile("" ::"v"(fa[0]), "v"(fa[1]), "v"(fa[2]), "v"(fa[3]), "v"(fb[0]), "v"(fb[1]), "v"(fb[2]), "v"(fb[3]));
       return;
     }
@@ -347,6 +347,7 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_pp_kernel(TnParams p) {
   bf16x8 fa2[8];
   auto read_a8 = [&](int bufoff, auto ks_c) {
     constexpr int ks = decltype(ks_c)::value;
+    if ((TN_ABLATE & 2) && bufoff >= 0) return;
 #pragma unroll
     for (int ii = 0; ii < 8; ++ii) {
       const unsigned a = fragA[ii] + (unsigned)bufoff;
@@ -369,6 +370,11 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_pp_kernel(TnParams p) {
     }
   };
   auto mma32 = [&]() {
+    if (TN_ABLATE & 4) {
+      asm volatile("" ::"v"(fa2[0]), "v"(fa2[1]), "v"(fa2[2]), "v"(fa2[3]), "v"(fa2[4]), "v"(fa2[5]), "v"(fa2[6]), "v"(fa2[7]), "v"(fb[0]), "v"(fb[1]),
+                   "v"(fb[2]), "v"(fb[3]));
+      return;
+    }
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ii = 0; ii < 8; ++ii)
