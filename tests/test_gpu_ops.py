@@ -114,6 +114,7 @@ def _ref_acc(A, B):
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 192, 64), (544, 768, 192), (1000, 260, 128), (257, 2304, 768), (37, 12, 64),
+                                   (1000, 264, 128), (333, 776, 256),   # N % 8 == 0, ragged tiles: line-shaped epilogue with out-of-range lanes
                                    (66000, 512, 128),      # 516 tiles, K <= 512: persistent workgroups, 3 tiles each
                                    (25216, 768, 64),       # 297 tiles: the 192-row tile variant
                                    (50000, 768, 64)])      # 588 tiles: the 224-row tile variant (uneven DMA split)
