@@ -19,6 +19,13 @@
 #include <type_traits>
 #include "common.h"
 
+#ifdef VITSSL_TN_STAMPS
+__device__ unsigned long long* g_tn_stamps = nullptr;     // [workgroup][wave group][8]
+extern "C" int vitssl_debug_set_tn_stamps(unsigned long long* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_tn_stamps), &p, sizeof(p)) == hipSuccess ? 0 : 1;
+}
+#endif
+
 namespace {
 
 constexpr int TN_T = 256;          // output tile edge
@@ -174,10 +181,11 @@ typedef __attribute__((ext_vector_type(8))) short tn_s16x8;
 #ifndef TN_ABLATE
 #define TN_ABLATE 0
 #endif
-// phases (barrier pairs) per K-tile: 4 = 16 MFMAs per phase, 2 = 32 MFMAs per phase (half the barriers, one
-// K-tile of prefetch distance instead of 1.5)
-#ifndef TN_PHASES
-#define TN_PHASES 2
+// (A K-tile is two phases of 32 MFMAs per wave; round 2's four phases of 16 -- twice the barriers -- were 2-4 % slower and are gone.)
+// 1 = s_setprio 1 around the MFMA clusters, 2 = raised priority for the LOAD parts; 0 (default): none -- interleaved A/B on the four
+// ViT-B weight-gradient shapes: 0 is 1.0-1.9 % faster than 1, 2 is 0.6-1.3 % faster than 1 (round 2's loop gained 10 % from 1)
+#ifndef TN_SETPRIO
+#define TN_SETPRIO 0
 #endif
 
 
@@ -205,8 +213,10 @@ __device__ __forceinline__ void tn_section() {
 
 __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_pp_kernel(TnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BUF = 2 * TN_TILE_BYTES;               // one K-tile: A tile then B tile
-  constexpr unsigned OOBV = 0x80000000u;
+  // LDS: [A tile of buffer 0][A of buffer 1][B of buffer 0][B of buffer 1]: both buffers of an operand are within the 64 KiB reach
+  // of a ds_read immediate, so the fragment reads of either buffer use ONE address register per 16-column tile (the K loop is
+  // unrolled by two, the buffer is a compile-time constant)
+  constexpr int B_BASE = 2 * TN_TILE_BYTES;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int w1 = wave >> 2, w2 = wave & 3;
@@ -226,8 +236,6 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_pp_kernel(TnParams p) {
   if (ch_end > total_chunks) ch_end = total_chunks;
   const int nk = ch_begin < ch_end ? (int)(ch_end - ch_begin) : 0;   // empty split: writes a zero slab
 
-  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((unsigned long long)p.M * p.N1 * 2ull), 0x00020000);
-  __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)((unsigned long long)p.M * p.N2 * 2ull), 0x00020000);
 
   // staging slots of this wave: unit X_kh = rows 32 h + [0, 32) of the operand tile; slot e covers rows
   // 32 h + 4 wave + 2 e + (lane >> 5)
@@ -244,25 +252,30 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_pp_kernel(TnParams p) {
       voffA[h][e] = (unsigned)((row * (long long)p.N1 + c1) * 2 + sch16 * 16);
       voffB[h][e] = (unsigned)((row * (long long)p.N2 + c2) * 2 + sch16 * 16);
       ldsA[h][e] = r0 * 512;
-      ldsB[h][e] = TN_TILE_BYTES + r0 * 512;
+      ldsB[h][e] = B_BASE + r0 * 512;
     }
-  const unsigned stepA = (unsigned)TN_KM * (unsigned)p.N1 * 2u, stepB = (unsigned)TN_KM * (unsigned)p.N2 * 2u;
-  // byte offset of K-tile t's first row (OOBV past the end of this workgroup's range: zero fill, no traffic)
-  auto baseA = [&](int t) -> unsigned { return t < nk ? (unsigned)(ch_begin + t) * stepA : OOBV; };
-  auto baseB = [&](int t) -> unsigned { return t < nk ? (unsigned)(ch_begin + t) * stepB : OOBV; };
+  // The K-tile's position lives in the buffer DESCRIPTOR (scalar arithmetic), not in the lanes' offsets: window = rows of K-tile t
+  // .. M - 1 of the operand (rows past M read as zero; a K-tile past this workgroup's range gets an empty window: zero fill, no
+  // traffic).  The K loop's LOAD parts share their SIMD with the partner wave's MFMA cluster and get about one issue slot per MFMA
+  // (tools/tn_stamps.py: 42 instructions took 720 cycles), so every vector instruction removed from them counts.
+  auto window = [&](const bf16_t* base, int ncols, int t) {
+    const long long row0 = (ch_begin + t) * (long long)TN_KM;
+    const long long rows = t < nk ? p.M - row0 : 0;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + row0 * ncols), 0, (int)(rows * ncols * 2), 0x00020000);
+  };
   auto stage_a = [&](int t, int bufsel, auto h_c) {
     constexpr int h = decltype(h_c)::value;
-    const unsigned b = baseA(t);
     if ((TN_ABLATE & 1) && t >= 2) return;
+    __amdgpu_buffer_rsrc_t rs = window(p.A, p.N1, t);
 #pragma unroll
-    for (int e = 0; e < 2; ++e) tn_dma16(rsA, smem + bufsel * BUF + ldsA[h][e], voffA[h][e] + b);
+    for (int e = 0; e < 2; ++e) tn_dma16(rs, smem + bufsel * TN_TILE_BYTES + ldsA[h][e], voffA[h][e]);
   };
   auto stage_b = [&](int t, int bufsel, auto h_c) {
     constexpr int h = decltype(h_c)::value;
-    const unsigned b = baseB(t);
     if ((TN_ABLATE & 1) && t >= 2) return;
+    __amdgpu_buffer_rsrc_t rs = window(p.B, p.N2, t);
 #pragma unroll
-    for (int e = 0; e < 2; ++e) tn_dma16(rsB, smem + bufsel * BUF + ldsB[h][e], voffB[h][e] + b);
+    for (int e = 0; e < 2; ++e) tn_dma16(rs, smem + bufsel * TN_TILE_BYTES + ldsB[h][e], voffB[h][e]);
   };
 
   f32x4 acc[8][4];
@@ -285,74 +298,46 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_pp_kernel(TnParams p) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) fragA[i] = lds0 + r0 * 512 + (((w1 * 8 + i) ^ tn_f(r0)) << 5) + 8 * pp_;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) fragB[j] = lds0 + TN_TILE_BYTES + r0 * 512 + (((w2 * 4 + j) ^ tn_f(r0)) << 5) + 8 * pp_;
+    for (int j = 0; j < 4; ++j) fragB[j] = lds0 + B_BASE + r0 * 512 + (((w2 * 4 + j) ^ tn_f(r0)) << 5) + 8 * pp_;
   }
-  s16x4 ta[4][2], tb[4][2];                            // raw halves (rows r0.., rows r0 + 4..) of the fragments being read
-  bf16x8 fa[4], fb[4];
-  auto read_b = [&](int bufoff, auto ks_c) {
-    constexpr int ks = decltype(ks_c)::value;
-    if ((TN_ABLATE & 2) && bufoff >= 0) return;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const unsigned a = fragB[j] + (unsigned)bufoff;
-      tn_ds_tr<ks * 16384>(tb[j][0], a);
-      tn_ds_tr<ks * 16384 + 2048>(tb[j][1], a);
-    }
-  };
-  auto read_a = [&](int bufoff, auto ks_c, auto ih_c) {
-    constexpr int ks = decltype(ks_c)::value, ih = decltype(ih_c)::value;
-    if ((TN_ABLATE & 2) && bufoff >= 0) return;
-#pragma unroll
-    for (int ii = 0; ii < 4; ++ii) {
-      const unsigned a = fragA[4 * ih + ii] + (unsigned)bufoff;
-      tn_ds_tr<ks * 16384>(ta[ii][0], a);
-      tn_ds_tr<ks * 16384 + 2048>(ta[ii][1], a);
-    }
-  };
-  auto landed = [&](bool with_b) {                     // after the barrier: wait for the reads, assemble the operands
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    if (with_b) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const tn_s16x8 v = {tb[j][0][0], tb[j][0][1], tb[j][0][2], tb[j][0][3], tb[j][1][0], tb[j][1][1], tb[j][1][2], tb[j][1][3]};
-        fb[j] = __builtin_bit_cast(bf16x8, v);
-      }
-    }
-#pragma unroll
-    for (int ii = 0; ii < 4; ++ii) {
-      const tn_s16x8 v = {ta[ii][0][0], ta[ii][0][1], ta[ii][0][2], ta[ii][0][3], ta[ii][1][0], ta[ii][1][1], ta[ii][1][2], ta[ii][1][3]};
-      fa[ii] = __builtin_bit_cast(bf16x8, v);
-    }
-  };
-  auto mma = [&](auto ih_c) {
-    constexpr int ih = decltype(ih_c)::value;
-    if (TN_ABLATE & 4) {
-      asm volatile("" ::"v"(fa[0]), "v"(fa[1]), "v"(fa[2]), "v"(fa[3]), "v"(fb[0]), "v"(fb[1]), "v"(fb[2]), "v"(fb[3]));
-      return;
-    }
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[4 * ih + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[ii], acc[4 * ih + ii][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-  };
+  s16x4 tb[4][2];                                      // raw halves (rows r0.., rows r0 + 4..) of the fragments being read
+  bf16x8 fb[4];
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
 
-#if TN_PHASES == 2
+#ifdef VITSSL_TN_STAMPS
+  // diagnostic build (tools/tn_stamps.py): time (10 ns ticks) wave 0 / wave 4 spend in each part of a phase, summed over the K loop:
+  // 0 LOAD issue (reads + DMA), 1 vmcnt wait, 2 barrier, 3 lgkmcnt wait, 4 MFMA issue, 5 barrier
+  unsigned long long tseg[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = 0;
+#define TSTAMP(i)                                                    \
+  do {                                                               \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    const unsigned long long tn_ = __builtin_amdgcn_s_memrealtime();  \
+    tseg[i] += tn_ - tprev;                                          \
+    tprev = tn_;                                                     \
+    __builtin_amdgcn_sched_barrier(0);                               \
+  } while (0)
+#else
+#define TSTAMP(i) \
+  do {            \
+  } while (0)
+#endif
   s16x4 ta2[8][2];
   bf16x8 fa2[8];
-  auto read_a8 = [&](int bufoff, auto ks_c) {
-    constexpr int ks = decltype(ks_c)::value;
-    if ((TN_ABLATE & 2) && bufoff >= 0) return;
+  // the 24 transposed reads of one phase: buffer and contraction half are compile-time (immediate offsets), no address arithmetic
+  auto read_frags = [&](auto buf_c, auto ks_c) {
+    constexpr int IMM = decltype(buf_c)::value * TN_TILE_BYTES + decltype(ks_c)::value * 16384;
+    if (TN_ABLATE & 2) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      tn_ds_tr<IMM>(tb[j][0], fragB[j]);
+      tn_ds_tr<IMM + 2048>(tb[j][1], fragB[j]);
+    }
 #pragma unroll
     for (int ii = 0; ii < 8; ++ii) {
-      const unsigned a = fragA[ii] + (unsigned)bufoff;
-      tn_ds_tr<ks * 16384>(ta2[ii][0], a);
-      tn_ds_tr<ks * 16384 + 2048>(ta2[ii][1], a);
+      tn_ds_tr<IMM>(ta2[ii][0], fragA[ii]);
+      tn_ds_tr<IMM + 2048>(ta2[ii][1], fragA[ii]);
     }
   };
   auto landed8 = [&]() {
@@ -375,12 +360,32 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_pp_kernel(TnParams p) {
                    "v"(fb[2]), "v"(fb[3]));
       return;
     }
-    __builtin_amdgcn_s_setprio(1);
+    if (TN_SETPRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ii = 0; ii < 8; ++ii)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa2[ii], acc[ii][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
+    if (TN_SETPRIO == 1) __builtin_amdgcn_s_setprio(0);
+  };
+  // one phase = contraction half ks (32 rows) of K-tile t in buffer b: all 32 MFMAs of the wave; the ks half of K-tile t + 1 goes
+  // into the other buffer
+  auto phase = [&](auto buf_c, auto ks_c, int t, bool skip_section) {
+    constexpr int bsel = decltype(buf_c)::value;
+    if (TN_SETPRIO == 2) __builtin_amdgcn_s_setprio(2);
+    read_frags(buf_c, ks_c);
+    stage_b(t + 1, bsel ^ 1, ks_c);
+    stage_a(t + 1, bsel ^ 1, ks_c);
+    TSTAMP(0);
+    tn_wait_vmcnt<4>();
+    TSTAMP(1);
+    tn_section();
+    TSTAMP(2);
+    landed8();
+    TSTAMP(3);
+    mma32();
+    TSTAMP(4);
+    if (!skip_section) tn_section();
+    TSTAMP(5);
   };
   if (nk > 0) {
     stage_b(0, 0, I0{});
@@ -390,78 +395,20 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_pp_kernel(TnParams p) {
     tn_wait_vmcnt<4>();                                // the ks-0 halves of K-tile 0 have landed
     tn_section();
     if (w1 == 1) tn_section();                         // waves 4-7 run one barrier behind waves 0-3
-    int buf = 0;
-    for (int t = 0; t < nk; ++t) {
-      const int cur = buf * BUF;
-      // phase A: ks 0 (all 32 MFMAs); the ks-0 halves of K-tile t+1 go into the other buffer
-      read_b(cur, I0{});
-      read_a8(cur, I0{});
-      stage_b(t + 1, buf ^ 1, I0{});
-      stage_a(t + 1, buf ^ 1, I0{});
-      tn_wait_vmcnt<4>();
-      tn_section();
-      landed8();
-      mma32();
-      tn_section();
-      // phase B: ks 1
-      read_b(cur, I1{});
-      read_a8(cur, I1{});
-      stage_b(t + 1, buf ^ 1, I1{});
-      stage_a(t + 1, buf ^ 1, I1{});
-      tn_wait_vmcnt<4>();
-      tn_section();
-      landed8();
-      mma32();
-      if (!(t + 1 == nk && w1 == 1)) tn_section();
-      buf ^= 1;
+#ifdef VITSSL_TN_STAMPS
+    tprev = __builtin_amdgcn_s_memrealtime();
+#endif
+    for (int t = 0; t < nk; t += 2) {
+      phase(I0{}, I0{}, t, false);
+      phase(I0{}, I1{}, t, t + 1 == nk && w1 == 1);    // (waves 4-7 leave the stagger at the end)
+      if (t + 1 >= nk) break;
+      phase(I1{}, I0{}, t + 1, false);
+      phase(I1{}, I1{}, t + 1, t + 2 == nk && w1 == 1);
     }
-#else
-  if (nk > 0) {
-    stage_b(0, 0, I0{});
-    stage_a(0, 0, I0{});
-    stage_b(0, 0, I1{});
-    stage_a(0, 0, I1{});
-    stage_b(1, 1, I0{});
-    stage_a(1, 1, I0{});
-    tn_wait_vmcnt<8>();                                // Bk0, Ak0 of K-tile 0 have landed
-    tn_section();
-    if (w1 == 1) tn_section();                         // waves 4-7 run one barrier behind waves 0-3
-    int buf = 0;
-    for (int t = 0; t < nk; ++t) {
-      const int cur = buf * BUF;
-      // p0: ks 0, n1 tiles 0-3
-      read_b(cur, I0{});
-      read_a(cur, I0{}, I0{});
-      stage_b(t + 1, buf ^ 1, I1{});
-      tn_section();
-      landed(true);
-      mma(I0{});
-      tn_section();
-      // p1: ks 0, n1 tiles 4-7
-      read_a(cur, I0{}, I1{});
-      stage_a(t + 1, buf ^ 1, I1{});
-      tn_wait_vmcnt<8>();
-      tn_section();
-      landed(false);
-      mma(I1{});
-      tn_section();
-      // p2: ks 1, n1 tiles 0-3
-      read_b(cur, I1{});
-      read_a(cur, I1{}, I0{});
-      stage_b(t + 2, buf, I0{});
-      tn_section();
-      landed(true);
-      mma(I0{});
-      tn_section();
-      // p3: ks 1, n1 tiles 4-7
-      read_a(cur, I1{}, I1{});
-      stage_a(t + 2, buf, I0{});
-      tn_wait_vmcnt<8>();
-      tn_section();
-      landed(false);
-      mma(I1{});
-      if (!(t + 1 == nk && w1 == 1)) tn_section();
-      buf ^= 1;
+#ifdef VITSSL_TN_STAMPS
+    if (g_tn_stamps && lane == 0 && (wave & 3) == 0) {
+      for (int i = 0; i < 6; ++i) g_tn_stamps[((size_t)blockIdx.x * 2 + w1) * 8 + i] = tseg[i];
+      g_tn_stamps[((size_t)blockIdx.x * 2 + w1) * 8 + 6] = (unsigned long long)nk;
     }
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing zero-fill DMA retired before the LDS is released
@@ -620,7 +567,7 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_fp8_kernel(Tn8Params p)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       fb[j] = i32x8{rb[j][0][0], rb[j][0][1], rb[j][1][0], rb[j][1][1], rb[j][2][0], rb[j][2][1], rb[j][3][0], rb[j][3][1]};
-    __builtin_amdgcn_s_setprio(1);
+    if (TN_SETPRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const i32x8 fa = {ra[i][0][0], ra[i][0][1], ra[i][1][0], ra[i][1][1], ra[i][2][0], ra[i][2][1], ra[i][3][0], ra[i][3][1]};
@@ -628,7 +575,7 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_fp8_kernel(Tn8Params p)
       for (int j = 0; j < 4; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb[j], fa, acc[i][j], 0, 0, 0, 0, 0, 0);
     }
-    __builtin_amdgcn_s_setprio(0);
+    if (TN_SETPRIO == 1) __builtin_amdgcn_s_setprio(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
