@@ -211,6 +211,10 @@ __device__ __forceinline__ void tn_section() {
   asm volatile("" ::: "memory");
 }
 
+// Tried in round 3 and dropped (git history: "single-stream" kernel): all 8 waves in step, every wave reading the NEXT phase's
+// fragments into a second register set in the shadow of its own MFMAs (inline-asm MFMAs interleaved 1:1 with the 24 reads + DMA,
+// one barrier per phase, 230 VGPRs): correct, but 5-8 % SLOWER than this loop on the four ViT-B shapes -- with nothing else to run
+// at the phase's wait + barrier the matrix pipe drains twice per K-tile.
 __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_pp_kernel(TnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // LDS: [A tile of buffer 0][A of buffer 1][B of buffer 0][B of buffer 1]: both buffers of an operand are within the 64 KiB reach
