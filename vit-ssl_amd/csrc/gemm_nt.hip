@@ -79,6 +79,13 @@
 #define NT_LDS_T 1
 #endif
 // start-up stagger window of the ping-pong kernel in tile times (VITSSL_NT_STAGGER overrides)
+// epilogues whose launches stagger (bit = VITSSL_EPI_* value).  Spreading the workgroups in time costs L2 sharing (the workgroups
+// of a raster group are no longer at the same k): FETCH_SIZE per launch with / without stagger (tools/fetch_ab.sh): plain bf16,
+// 224-row tiles 415 / 282 MB, residual 547 / 412, dGELU 692 / 645, GELU 347 / 344.  Whole step (same box, alternating, ms): all
+// 33.12, residual + dGELU 33.13, dGELU only 33.26, none 33.42 -> only the two epilogues that are bound by their own traffic stagger.
+#ifndef NT_STAGGER_EPIS_DEFAULT
+#define NT_STAGGER_EPIS_DEFAULT 0x18
+#endif
 #ifndef NT_STAGGER_DEFAULT
 #define NT_STAGGER_DEFAULT 1.0f
 #endif
@@ -1356,10 +1363,16 @@ int launch_pp(NtParams p, hipStream_t s) {
     // (N = 3072, K = 768), residual 241 -> 231 (K = 3072), plain stores -1.5..-3 %, never slower; whole step 34.29 -> 34.05 ms.
     stagger_scale = e ? (float)atof(e) : NT_STAGGER_DEFAULT;
   }
+  // which epilogues stagger (bit = VITSSL_EPI_* value; VITSSL_NT_STAGGER_EPIS overrides): see NT_STAGGER_EPIS_DEFAULT
+  static int stagger_mask = -1;
+  if (stagger_mask < 0) {
+    const char* e = getenv("VITSSL_NT_STAGGER_EPIS");
+    stagger_mask = e ? (int)strtol(e, nullptr, 0) : NT_STAGGER_EPIS_DEFAULT;
+  }
   const float epi_us = EPI == VITSSL_EPI_BF16 ? 2.f : EPI == VITSSL_EPI_GELU ? 7.f : EPI == VITSSL_EPI_DGELU ? 5.f
                        : EPI == VITSSL_EPI_RESID ? 8.f : 4.f;
   const float tile_us = (float)(p.K * p.esz / 128) * 1.45f * (float)CFG::MI / 8.f + epi_us;
-  p.stagger = (int)(stagger_scale * tile_us * 100.f);
+  p.stagger = ((stagger_mask >> EPI) & 1) ? (int)(stagger_scale * tile_us * 100.f) : 0;
   nt_note_grid((int)grid);
   hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, CFG, F8>), dim3((unsigned)grid), dim3(CFG::THREADS), LDS, s, p);
   VS_CHECK_LAUNCH("gemm_nt_pp");
