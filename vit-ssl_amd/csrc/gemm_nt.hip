@@ -79,6 +79,12 @@
 #define NT_LDS_T 1
 #endif
 // start-up stagger window of the ping-pong kernel in tile times (VITSSL_NT_STAGGER overrides)
+// 1: s_setprio 1 around the MFMA clusters of the ping-pong loop.  Round 2 measured it neutral; with the leaner loops of round 3 it
+// costs 0.5-1.5 % on 15 of 16 shape x epilogue pairs (interleaved A/B, profiles/r03_tls_ab.txt): 8 more scalar instructions per
+// K-tile in loops whose LOAD parts are bound by issue slots (see gemm_tn.hip).  Default off.
+#ifndef NT_SETPRIO
+#define NT_SETPRIO 0
+#endif
 // epilogues whose launches stagger (bit = VITSSL_EPI_* value).  Spreading the workgroups in time costs L2 sharing (the workgroups
 // of a raster group are no longer at the same k): FETCH_SIZE per launch with / without stagger (tools/fetch_ab.sh): plain bf16,
 // 224-row tiles 415 / 282 MB, residual 547 / 412, dGELU 692 / 645, GELU 347 / 344.  Whole step (same box, alternating, ms): all
@@ -1172,7 +1178,7 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_nt_pp_kernel(NtParams p)
                    "v"(fb[nh][0][0]), "v"(fb[nh][1][0]), "v"(fb[nh][0][1]), "v"(fb[nh][1][1]));
       return;
     }
-    __builtin_amdgcn_s_setprio(1);
+    if (NT_SETPRIO) __builtin_amdgcn_s_setprio(1);
     if constexpr (F8) {
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
@@ -1192,7 +1198,7 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_nt_pp_kernel(NtParams p)
             acc[2 * nh + jj][4 * mh + ii] =
                 __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nh][kk][jj], fa[kk][ii], acc[2 * nh + jj][4 * mh + ii], 0, 0, 0);
     }
-    __builtin_amdgcn_s_setprio(0);
+    if (NT_SETPRIO) __builtin_amdgcn_s_setprio(0);
   };
   auto section = [&]() {                               // end of a LOAD or COMPUTE part
     // the raw s_barrier carries no fence: the empty asm statements keep the optimiser from moving
