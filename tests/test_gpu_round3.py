@@ -48,3 +48,46 @@ def test_reserved_cus_take_effect_after_a_forward(monkeypatch):
             L.call("vitssl_set_reserved_cus", -3)
     finally:
         L.call("vitssl_set_reserved_cus", before)
+
+
+def test_nt_line_shaped_epilogue_matches_plain_kernel_on_ragged_shapes():
+    """The ping-pong kernel's epilogue moves every 16-row tile through a per-wave LDS window and stores / loads whole 128-byte lines
+    (csrc/gemm_nt.hip, NT_LDS_T); N % 8 != 0 and tiny grids run the round-1 kernel with accumulator-layout accesses.  Shapes whose
+    M, N are ragged against the 256 x 256 tile in every way (last row tile 1..255 rows, last column tile 8..248 columns, several
+    tile rounds per workgroup at K = 64): bf16 / fp32 outputs against an fp64 product, residual + dropout against the exported mask,
+    dGELU against the stored g', and the bf16 image must be the rounding of the fp32 image bit for bit."""
+    from vitssl_hip import _lib as L, ops
+    g = torch.Generator().manual_seed(7)
+    cus = torch.cuda.get_device_properties(DEV).multi_processor_count
+    shapes = [(257, 8, 64), (1000, 24, 128), (513, 72, 320), (4097, 520, 64), (777, 1032, 192), (256 * cus + 300, 264, 64), (33, 2056, 128)]
+    for (M, N, K) in shapes:
+        A = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16)
+        B = (torch.randn(N, K, generator=g) * 0.5).to(torch.bfloat16)
+        bias = torch.randn(N, generator=g)
+        acc = (A.double() @ B.double().t()).float() + bias
+        Ad, Bd, bd = A.to(DEV), B.to(DEV), bias.to(DEV)
+        o32 = torch.full((M + 1, N), 7.0, device=DEV)                 # one guard row: nothing may be written past M
+        ops.gemm_nt(Ad, Bd, o32[:M], L.EPI_F32, bias=bd)
+        assert float((o32[:M].cpu() - acc).abs().max()) < 1e-3 * (1 + float(acc.abs().max())), (M, N, K)
+        assert bool((o32[M] == 7.0).all()), (M, N, K)
+        o16 = torch.full((M + 1, N), 7.0, dtype=torch.bfloat16, device=DEV)
+        cs = torch.zeros(N, device=DEV)
+        ops.gemm_nt(Ad, Bd, o16[:M], L.EPI_BF16, bias=bd, colsum=cs)
+        assert torch.equal(o16[:M], o32[:M].to(torch.bfloat16)), (M, N, K)
+        assert bool((o16[M] == 7.0).all()), (M, N, K)
+        assert float((cs.cpu() - acc.sum(0)).abs().max()) < 2e-3 * (1 + float(acc.sum(0).abs().max())), (M, N, K)
+        # residual + dropout (fp32 in, fp32 out) and dGELU (bf16 operand in, bf16 out)
+        res = torch.randn(M, N, generator=g)
+        drop = ops.make_dropout(0.2, seed=3, site=5)
+        keep = ops.dropout_mask(M, N, drop, DEV).cpu().float()
+        scale = 65536.0 / (65536 - round(0.2 * 65536))
+        outr = torch.empty(M, N, device=DEV)
+        ops.gemm_nt(Ad, Bd, outr, L.EPI_RESID, bias=bd, aux=res.to(DEV), drop=drop)
+        ref = res + acc * keep * scale
+        assert float((outr.cpu() - ref).abs().max()) < 1e-3 * (1 + float(ref.abs().max())), (M, N, K)
+        gp = (torch.rand(M, N, generator=g) * 1.2).to(torch.bfloat16)
+        du = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        ops.gemm_nt(Ad, Bd, du, L.EPI_DGELU, aux=gp.to(DEV))
+        refd = ((A.double() @ B.double().t()).float() * gp.float()).to(torch.bfloat16)
+        d = (du.cpu().float() - refd.float()).abs()
+        assert bool((d <= refd.float().abs() * 2.0 ** -7 + 1e-3).all()), (M, N, K)
