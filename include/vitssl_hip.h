@@ -200,6 +200,21 @@ int64_t vitssl_gemm_tn_workspace_floats(int64_t M, int N1, int N2);
 int vitssl_gemm_bf16_tn(const void* A, const void* B, float* C, int64_t M, int N1, int N2, float* workspace,
                         int64_t workspace_floats, void* stream);
 
+/* Several weight gradients over the SAME M rows in one launch: C_j[N1_j, N2_j] (fp32) += A_j[M, N1_j]^T . B_j[M, N2_j], j < njobs <= 8
+ * (the four weight gradients of a transformer block: reference vit_core/encoder_block.py:40-53, feed_forward.py:26-28,
+ * attention.py:30-47 backward).  The tiles of all jobs share one split count, one launch and one reduce pass, which cuts the
+ * partial-tile traffic of vitssl_gemm_bf16_tn (one round of the CUs per launch, whatever the shape).  Workspace: at least
+ * vitssl_gemm_tn_batch_workspace_floats(jobs, njobs, M) floats (0 when every tile has a single owner).  N1, N2 % 8 == 0. */
+typedef struct {
+  const void* A; /* bf16 [M, N1] */
+  const void* B; /* bf16 [M, N2] */
+  float* C;      /* f32 [N1, N2], accumulated into */
+  int N1, N2;
+} vitssl_tn_job_t;
+int64_t vitssl_gemm_tn_batch_workspace_floats(const vitssl_tn_job_t* jobs, int njobs, int64_t M);
+int vitssl_gemm_bf16_tn_batch(const vitssl_tn_job_t* jobs, int njobs, int64_t M, float* workspace, int64_t workspace_floats,
+                              void* stream);
+
 /* ---- fused multi-head self-attention (vit_core/attention.py:20-23,86-103) ----------
  * qkv  bf16 [B, N, 3, H, dh]  (the fused projection output: q | k | v per token)
  * out  bf16 [B, N, H*dh]      (heads merged, ready for final_linear)

@@ -91,3 +91,37 @@ def test_nt_line_shaped_epilogue_matches_plain_kernel_on_ragged_shapes():
         refd = ((A.double() @ B.double().t()).float() * gp.float()).to(torch.bfloat16)
         d = (du.cpu().float() - refd.float()).abs()
         assert bool((d <= refd.float().abs() * 2.0 ** -7 + 1e-3).all()), (M, N, K)
+
+
+@pytest.mark.parametrize("M,dims", [(5000, [(768, 3072), (3072, 768), (768, 768), (2304, 768)]),      # a ViT-B block's four gradients
+                                    (1000, [(384, 1536), (264, 72)]),                                   # ragged tiles, short contraction
+                                    (300, [(8, 8)]),                                                    # one tile, one job
+                                    (64 * 40, [(2048, 4096), (4096, 2048)])])                           # more tiles than CUs: single owners, no partials
+def test_gemm_tn_batch_matches_single_launches(M, dims):
+    """vitssl_gemm_bf16_tn_batch: every job's C += A^T B, against an fp64 product and against one vitssl_gemm_bf16_tn per job."""
+    from vitssl_hip import ops
+    g = torch.Generator().manual_seed(M + len(dims))
+    jobs, refs, singles = [], [], []
+    for (N1, N2) in dims:
+        A = (torch.randn(M, N1, generator=g) * 0.5).to(torch.bfloat16)
+        B = (torch.randn(M, N2, generator=g) * 0.5).to(torch.bfloat16)
+        C0 = torch.randn(N1, N2, generator=g)
+        refs.append(C0.double() + A.double().t() @ B.double())
+        Ad, Bd = A.to(DEV), B.to(DEV)
+        jobs.append((Ad, Bd, C0.clone().to(DEV)))
+        c1 = C0.clone().to(DEV)
+        ops.gemm_tn(Ad, Bd, c1)
+        singles.append(c1)
+    ops.gemm_tn_batch(jobs)
+    ops.gemm_tn_batch(jobs[:0])                       # empty list: nothing to do
+    for (_, _, Cd), ref, c1 in zip(jobs, refs, singles):
+        scale = float(ref.abs().max())
+        assert float((Cd.double().cpu() - ref).abs().max()) < 2e-5 * scale
+        assert float((Cd - c1).abs().max()) < 1e-5 * scale        # same products, a different split: fp32 summation order only
+    # a second call accumulates on top
+    ops.gemm_tn_batch(jobs)
+    for (A, B, Cd), ref in zip(jobs, refs):
+        ref2 = ref + A.double().cpu().t() @ B.double().cpu()
+        assert float((Cd.double().cpu() - ref2).abs().max()) < 3e-5 * float(ref2.abs().max())
+    with pytest.raises(Exception, match="row counts"):
+        ops.gemm_tn_batch([jobs[0], (jobs[0][0][:-8], jobs[0][1][:-8], jobs[0][2])])

@@ -215,8 +215,21 @@ __device__ __forceinline__ void tn_section() {
 // fragments into a second register set in the shadow of its own MFMAs (inline-asm MFMAs interleaved 1:1 with the 24 reads + DMA,
 // one barrier per phase, 230 VGPRs): correct, but 5-8 % SLOWER than this loop on the four ViT-B shapes -- with nothing else to run
 // at the phase's wait + barrier the matrix pipe drains twice per K-tile.
-__global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_pp_kernel(TnParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+// One unit of work of the ping-pong loop: the K-tiles [ch_begin, ch_begin + nk) of the output tile at (c1, c2).
+struct TnUnit {
+  const bf16_t* A;
+  const bf16_t* B;
+  long long M;
+  int N1, N2;
+  int c1, c2;
+  long long ch_begin;
+  int nk;
+  float* dst;      // mode 0 / 1 / 2: the [N1, N2] matrix (a split's slab, or C); mode 3: a compact 256 x 256 slot
+  int mode;        // 0 store into a slab, 1 add into C (sole owner of the tile), 2 atomic add into C, 3 store the whole tile into a slot
+  int stamp_wg;    // diagnostic build: workgroup index of the stamp record, or -1
+};
+
+__device__ __forceinline__ void tn_pp_unit(const TnUnit& p, char* smem) {
   // LDS: [A tile of buffer 0][A of buffer 1][B of buffer 0][B of buffer 1]: both buffers of an operand are within the 64 KiB reach
   // of a ds_read immediate, so the fragment reads of either buffer use ONE address register per 16-column tile (the K loop is
   // unrolled by two, the buffer is a compile-time constant)
@@ -225,21 +238,9 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_pp_kernel(TnParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int w1 = wave >> 2, w2 = wave & 3;
 
-  const int ntiles = p.tiles1 * p.tiles2;
-  const int nwg = ntiles * p.splits;
-  const int xcd = blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7;
-  const int bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
-  const int split = bid / ntiles;
-  const int tile = bid - split * ntiles;
-  const int t1 = tile / p.tiles2, t2 = tile - t1 * p.tiles2;
-  const int c1 = t1 * TN_T, c2 = t2 * TN_T;
-
-  const long long total_chunks = (p.M + TN_KM - 1) / TN_KM;
-  const long long ch_begin = (long long)split * p.chunks_per_split;
-  long long ch_end = ch_begin + p.chunks_per_split;
-  if (ch_end > total_chunks) ch_end = total_chunks;
-  const int nk = ch_begin < ch_end ? (int)(ch_end - ch_begin) : 0;   // empty split: writes a zero slab
-
+  const int c1 = p.c1, c2 = p.c2;
+  const long long ch_begin = p.ch_begin;
+  const int nk = p.nk;
 
   // staging slots of this wave: unit X_kh = rows 32 h + [0, 32) of the operand tile; slot e covers rows
   // 32 h + 4 wave + 2 e + (lane >> 5)
@@ -410,15 +411,22 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_pp_kernel(TnParams p) {
       phase(I1{}, I1{}, t + 1, t + 2 == nk && w1 == 1);
     }
 #ifdef VITSSL_TN_STAMPS
-    if (g_tn_stamps && lane == 0 && (wave & 3) == 0) {
-      for (int i = 0; i < 6; ++i) g_tn_stamps[((size_t)blockIdx.x * 2 + w1) * 8 + i] = tseg[i];
-      g_tn_stamps[((size_t)blockIdx.x * 2 + w1) * 8 + 6] = (unsigned long long)nk;
+    if (g_tn_stamps && p.stamp_wg >= 0 && lane == 0 && (wave & 3) == 0) {
+      for (int i = 0; i < 6; ++i) g_tn_stamps[((size_t)p.stamp_wg * 2 + w1) * 8 + i] = tseg[i];
+      g_tn_stamps[((size_t)p.stamp_wg * 2 + w1) * 8 + 6] = (unsigned long long)nk;
     }
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing zero-fill DMA retired before the LDS is released
   }
 
-  float* dst = p.slabs ? p.slabs + (long long)split * p.N1 * p.N2 : p.C;
+  if (p.mode == 3) {                                    // the whole tile, compact: slot[n1 - c1][n2 - c2] (no bounds: the slot is private)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *(f32x4*)(p.dst + (w1 * 128 + i * 16 + (lane & 15)) * TN_T + w2 * 64 + j * 16 + 4 * (lane >> 4)) = acc[i][j];
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int n1 = c1 + w1 * 128 + i * 16 + (lane & 15);
@@ -427,16 +435,127 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_pp_kernel(TnParams p) {
     for (int j = 0; j < 4; ++j) {
       const int n2 = c2 + w2 * 64 + j * 16 + 4 * (lane >> 4);
       if (n2 >= p.N2) continue;
-      float* q = dst + (long long)n1 * p.N2 + n2;
-      if (p.slabs) {
+      float* q = p.dst + (long long)n1 * p.N2 + n2;
+      if (p.mode == 0) {
         *(f32x4*)q = acc[i][j];
-      } else if (p.direct) {
+      } else if (p.mode == 1) {
         *(f32x4*)q = *(const f32x4*)q + acc[i][j];
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) unsafeAtomicAdd(q + r, acc[i][j][r]);
       }
     }
+  }
+}
+
+__global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_pp_kernel(TnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int ntiles = p.tiles1 * p.tiles2;
+  const int nwg = ntiles * p.splits;
+  const int xcd = blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7;
+  const int bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
+  const int split = bid / ntiles;
+  const int tile = bid - split * ntiles;
+  const int t1 = tile / p.tiles2, t2 = tile - t1 * p.tiles2;
+  const long long total_chunks = (p.M + TN_KM - 1) / TN_KM;
+  const long long ch_begin = (long long)split * p.chunks_per_split;
+  long long ch_end = ch_begin + p.chunks_per_split;
+  if (ch_end > total_chunks) ch_end = total_chunks;
+  TnUnit u;
+  u.A = p.A;
+  u.B = p.B;
+  u.M = p.M;
+  u.N1 = p.N1;
+  u.N2 = p.N2;
+  u.c1 = t1 * TN_T;
+  u.c2 = t2 * TN_T;
+  u.ch_begin = ch_begin;
+  u.nk = ch_begin < ch_end ? (int)(ch_end - ch_begin) : 0;   // empty split: writes a zero slab
+  u.dst = p.slabs ? p.slabs + (long long)split * p.N1 * p.N2 : p.C;
+  u.mode = p.slabs ? 0 : (p.direct ? 1 : 2);
+  u.stamp_wg = (int)blockIdx.x;
+  tn_pp_unit(u, smem);
+}
+
+// ---- several weight gradients over the same rows in ONE launch (vitssl_gemm_bf16_tn_batch).
+// Why: a launch of the kernel above is one round of the CUs, splits = CUs / tiles, and writes CUs x 256 KiB of partial tiles that
+// tn_reduce_kernel reads back -- 66 MB each way whatever the shape, ~25 us per launch, for the four gradients of a transformer
+// block four times.  Here the tiles of all jobs form one list, unit u = split * T + tile (split-major: the workgroups running at the
+// same time work on the same rows of the operands, as before), and workgroup w takes units w, w + G, ...: the split count is
+// chosen for the whole list (tn_batch_plan), so fewer, longer units, one launch and one reduce.
+constexpr int TN_MAX_JOBS = 8;
+struct TnBatchParams {
+  const bf16_t* A[TN_MAX_JOBS];
+  const bf16_t* B[TN_MAX_JOBS];
+  float* C[TN_MAX_JOBS];
+  int N1[TN_MAX_JOBS], N2[TN_MAX_JOBS];
+  int tiles2[TN_MAX_JOBS];
+  int tile0[TN_MAX_JOBS + 1];    // first tile of every job in the list (tile0[njobs] = T)
+  int njobs;
+  long long M;
+  int splits, chunks_per_split;
+  float* slots;                  // [splits * T][256][256] partial tiles (unit-major), or nullptr when splits == 1
+};
+
+__global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_batch_kernel(TnBatchParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int T = p.tile0[p.njobs];
+  const int units = T * p.splits;
+  const int G = gridDim.x;
+  const int xcd = blockIdx.x & 7, qq = G >> 3, rr = G & 7;
+  const int bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
+  const long long total_chunks = (p.M + TN_KM - 1) / TN_KM;
+  for (int un = bid; un < units; un += G) {
+    const int split = un / T;
+    const int gt = un - split * T;
+    int j = 0;
+#pragma unroll
+    for (int q = 1; q < TN_MAX_JOBS; ++q)
+      if (q < p.njobs && gt >= p.tile0[q]) j = q;
+    const int lt = gt - p.tile0[j];
+    const int t1 = lt / p.tiles2[j], t2 = lt - t1 * p.tiles2[j];
+    const long long ch_begin = (long long)split * p.chunks_per_split;
+    long long ch_end = ch_begin + p.chunks_per_split;
+    if (ch_end > total_chunks) ch_end = total_chunks;
+    TnUnit u;
+    u.A = p.A[j];
+    u.B = p.B[j];
+    u.M = p.M;
+    u.N1 = p.N1[j];
+    u.N2 = p.N2[j];
+    u.c1 = t1 * TN_T;
+    u.c2 = t2 * TN_T;
+    u.ch_begin = ch_begin;
+    u.nk = ch_begin < ch_end ? (int)(ch_end - ch_begin) : 0;
+    u.dst = p.slots ? p.slots + (long long)un * (TN_T * TN_T) : p.C[j];
+    u.mode = p.slots ? 3 : 1;
+    u.stamp_wg = -1;
+    tn_pp_unit(u, smem);
+    tn_section();                                      // every wave is done with the LDS before the next unit's first DMA
+  }
+}
+
+// C_j[tile] += sum over splits of the tile's slots; one block = 32 rows of one tile
+__global__ __launch_bounds__(256) void tn_batch_reduce_kernel(TnBatchParams p) {
+  const int T = p.tile0[p.njobs];
+  const int gt = blockIdx.x >> 3, rblk = blockIdx.x & 7;
+  int j = 0;
+  for (int q = 1; q < p.njobs; ++q)
+    if (gt >= p.tile0[q]) j = q;
+  const int lt = gt - p.tile0[j];
+  const int t1 = lt / p.tiles2[j], t2 = lt - t1 * p.tiles2[j];
+  const int col = 4 * (threadIdx.x & 63);
+  const int n2 = t2 * TN_T + col;
+  if (n2 >= p.N2[j]) return;
+#pragma unroll 2
+  for (int r = threadIdx.x >> 6; r < 32; r += 4) {
+    const int row = rblk * 32 + r;
+    const int n1 = t1 * TN_T + row;
+    if (n1 >= p.N1[j]) break;
+    float* q = p.C[j] + (long long)n1 * p.N2[j] + n2;
+    f32x4 a = *(const f32x4*)q;
+    for (int s = 0; s < p.splits; ++s) a += *(const f32x4*)(p.slots + ((long long)s * T + gt) * (TN_T * TN_T) + row * TN_T + col);
+    *(f32x4*)q = a;
   }
 }
 
@@ -689,6 +808,115 @@ extern "C" int vitssl_gemm_bf16_tn(const void* A, const void* B, float* C, int64
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, s, C, p.slabs, n4, (long long)N1 * N2, p.splits);
     VS_CHECK_LAUNCH("gemm_tn_reduce");
+  }
+  return VITSSL_OK;
+}
+
+// ---- batch of weight gradients over the same M rows
+namespace {
+// Split count for a list of T tiles: minimises (rounds of the CUs) x (K-tiles per unit x 1.46 us + 9 us per unit: pipeline fill,
+// hand-over, slot store) plus the partial-tile traffic (0.15 us per 256 KiB partial written and read back).  The two constants are
+// fitted to whole-step measurements with forced split counts (VITSSL_TN_BATCH_SPLITS): ViT-B (108 tiles) 2 splits 33.27 ms,
+// 7: 33.49, 9: 33.91, 3: 35.69; ViT-S (38 tiles) 6 splits 14.35 ms, 13: 14.78, 4: 14.95, 20: 15.21, 8: 15.55.
+// 1 split = every tile has one owner: no partials.
+void tn_batch_plan(long long M, int T, int* splits, int* chunks_per_split) {
+  const long long total_chunks = (M + TN_KM - 1) / TN_KM;
+  const int G = vitssl_persistent_cus();
+  double best = 1e30;
+  int best_s = 1;
+  const long long smax = total_chunks < 64 ? total_chunks : 64;
+  for (long long sp = 1; sp <= smax; ++sp) {
+    const long long cps = (total_chunks + sp - 1) / sp;
+    const long long s_eff = (total_chunks + cps - 1) / cps;
+    if (s_eff != sp) continue;                                  // same partition as a smaller count
+    const long long units = (long long)T * sp;
+    const long long rounds = (units + G - 1) / G;
+    const double cost = (double)rounds * ((double)cps * 1.46 + 9.0) + (sp > 1 ? (double)units * 0.15 : 0.0);
+    if (cost < best) {
+      best = cost;
+      best_s = (int)sp;
+    }
+  }
+  static int forced = -1;                                       // VITSSL_TN_BATCH_SPLITS: force the split count (developer knob)
+  if (forced < 0) {
+    const char* e = getenv("VITSSL_TN_BATCH_SPLITS");
+    forced = e ? atoi(e) : 0;
+  }
+  if (forced > 0 && forced <= total_chunks) best_s = forced;
+  *chunks_per_split = (int)((total_chunks + best_s - 1) / best_s);
+  *splits = (int)((total_chunks + *chunks_per_split - 1) / *chunks_per_split);
+}
+int tn_batch_tiles(const vitssl_tn_job_t* jobs, int njobs, TnBatchParams* p) {
+  int t = 0;
+  for (int j = 0; j < njobs; ++j) {
+    p->tile0[j] = t;
+    p->tiles2[j] = (jobs[j].N2 + TN_T - 1) / TN_T;
+    t += ((jobs[j].N1 + TN_T - 1) / TN_T) * p->tiles2[j];
+  }
+  p->tile0[njobs] = t;
+  return t;
+}
+}  // namespace
+
+extern "C" int64_t vitssl_gemm_tn_batch_workspace_floats(const vitssl_tn_job_t* jobs, int njobs, int64_t M) {
+  if (!jobs || njobs <= 0 || njobs > TN_MAX_JOBS || M <= 0) return 0;
+  TnBatchParams p;
+  const int T = tn_batch_tiles(jobs, njobs, &p);
+  int sp, cps;
+  tn_batch_plan(M, T, &sp, &cps);
+  return sp > 1 ? (int64_t)sp * T * TN_T * TN_T : 0;
+}
+
+extern "C" int vitssl_gemm_bf16_tn_batch(const vitssl_tn_job_t* jobs, int njobs, int64_t M, float* workspace, int64_t workspace_floats,
+                                         void* stream) {
+  VS_CHECK_ARG(jobs && njobs > 0 && njobs <= TN_MAX_JOBS, "gemm_tn_batch: 1..%d jobs", TN_MAX_JOBS);
+  VS_CHECK_ARG(M > 0, "gemm_tn_batch: empty problem");
+  TnBatchParams p;
+  for (int j = 0; j < njobs; ++j) {
+    const vitssl_tn_job_t& q = jobs[j];
+    VS_CHECK_ARG(q.A && q.B && q.C, "gemm_tn_batch: job %d: null operand", j);
+    VS_CHECK_ARG(q.N1 > 0 && q.N2 > 0 && q.N1 % 8 == 0 && q.N2 % 8 == 0, "gemm_tn_batch: job %d: N1=%d N2=%d must be positive multiples of 8", j,
+                 q.N1, q.N2);
+    VS_CHECK_ARG((unsigned long long)M * q.N1 * 2ull < (1ull << 31) && (unsigned long long)M * q.N2 * 2ull < (1ull << 31),
+                 "gemm_tn_batch: job %d: operand larger than 2 GiB", j);
+    p.A[j] = (const bf16_t*)q.A;
+    p.B[j] = (const bf16_t*)q.B;
+    p.C[j] = q.C;
+    p.N1[j] = q.N1;
+    p.N2[j] = q.N2;
+  }
+  for (int j = njobs; j < TN_MAX_JOBS; ++j) {
+    p.A[j] = p.B[j] = nullptr;
+    p.C[j] = nullptr;
+    p.N1[j] = p.N2[j] = p.tiles2[j] = 0;
+  }
+  const int T = tn_batch_tiles(jobs, njobs, &p);
+  for (int j = njobs + 1; j <= TN_MAX_JOBS; ++j) p.tile0[j] = T;
+  p.njobs = njobs;
+  p.M = M;
+  tn_batch_plan(M, T, &p.splits, &p.chunks_per_split);
+  const long long need = p.splits > 1 ? (long long)p.splits * T * TN_T * TN_T : 0;
+  VS_CHECK_ARG(need == 0 || (workspace && workspace_floats >= need), "gemm_tn_batch: workspace of %lld floats needed (vitssl_gemm_tn_batch_workspace_floats)",
+               need);
+  p.slots = need ? workspace : nullptr;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
+    if (e != hipSuccess) {
+      vitssl_set_error("gemm_tn_batch: cannot raise dynamic LDS: %s", hipGetErrorString(e));
+      return VITSSL_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const long long units = (long long)T * p.splits;
+  const long long cus = vitssl_persistent_cus();
+  const unsigned grid = (unsigned)(units < cus ? units : cus);
+  hipLaunchKernelGGL(gemm_tn_batch_kernel, dim3(grid), dim3(TN_THREADS), TN_LDS_BYTES, s, p);
+  VS_CHECK_LAUNCH("gemm_tn_batch");
+  if (p.slots) {
+    hipLaunchKernelGGL(tn_batch_reduce_kernel, dim3((unsigned)T * 8u), dim3(256), 0, s, p);
+    VS_CHECK_LAUNCH("gemm_tn_batch_reduce");
   }
   return VITSSL_OK;
 }

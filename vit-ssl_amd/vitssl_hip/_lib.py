@@ -23,6 +23,11 @@ class Embed(C.Structure):
                 ("tokens", C.c_int), ("out_tokens", C.c_int), ("tok_offset", C.c_int)]
 
 
+class TnJob(C.Structure):
+    """vitssl_tn_job_t"""
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("N1", C.c_int), ("N2", C.c_int)]
+
+
 class Gemm(C.Structure):
     _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("M", C.c_int64), ("N", C.c_int), ("K", C.c_int),
                 ("epilogue", C.c_int), ("bias", C.c_void_p), ("aux", C.c_void_p), ("out0", C.c_void_p),
@@ -46,6 +51,7 @@ PROTOTYPES = {
     "vitssl_grad_mask_cast": [_vp, _vp, _vp, Dropout, _i64, _i, _vp],
     "vitssl_gemm_bf16_nt": [C.POINTER(Gemm), _vp],
     "vitssl_gemm_bf16_tn": [_vp, _vp, _vp, _i64, _i, _i, _vp, _i64, _vp],
+    "vitssl_gemm_bf16_tn_batch": [C.POINTER(TnJob), _i, _i64, _vp, _i64, _vp],
     "vitssl_gemm_fp8_nt": [C.POINTER(Gemm), C.POINTER(Fp8Gemm), _vp],
     "vitssl_gemm_fp8_tn": [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _i64, _vp],
     "vitssl_quantize_fp8": [_vp, _vp, _i64, _vp],
@@ -119,6 +125,8 @@ def lib():
     l.vitssl_version.argtypes = []
     l.vitssl_gemm_tn_workspace_floats.restype = C.c_int64
     l.vitssl_gemm_tn_workspace_floats.argtypes = [C.c_int64, C.c_int, C.c_int]
+    l.vitssl_gemm_tn_batch_workspace_floats.restype = C.c_int64
+    l.vitssl_gemm_tn_batch_workspace_floats.argtypes = [C.POINTER(TnJob), C.c_int, C.c_int64]
     l.vitssl_gemm_fp8_tn_workspace_floats.restype = C.c_int64
     l.vitssl_gemm_fp8_tn_workspace_floats.argtypes = [C.c_int64, C.c_int, C.c_int]
     l.vitssl_embed_bwd_workspace_floats.restype = C.c_int64

@@ -519,26 +519,42 @@ class EncoderStack:
         delta = w(bw + "delta", (B, H, T), F32, dev)
         gv = st.gview
         last = self.L - 1
+        # The four weight gradients of a block run as ONE launch at the end of the block's backward (ops.gemm_tn_batch: one split
+        # count and one reduce pass for all their tiles instead of four rounds of the CUs with 66 MB of partial tiles each).  Their
+        # gradient operands must then all be alive at that point: the LayerNorm-2 backward writes its bf16 image into a second
+        # buffer (gm2) instead of over gm.  VITSSL_TN_BATCH=0: one launch per gradient, as before.
+        batch = _os.environ.get("VITSSL_TN_BATCH", "1") != "0"
+        gm2 = w(bw + "gm2", (M, D), BF16, dev) if batch else gm
         # top of the chain: dropout-mask + cast of g, and the last block's linear_out bias grad
         ops.grad_mask_cast(g, gm, gv(self._n(last, "feed_forward.linear_out.bias")), self._drop(last, 2, seed, training))
         for i in range(last, -1, -1):
             s = rec["blocks"][i]
             a_ = self.bp[i] + "self_attention."
             # MLP
+            wgrads = [(gm, s["a"], gv(self._n(i, "feed_forward.linear_out.weight"), (D, F))),
+                      (du, s["h2"], gv(self._n(i, "feed_forward.linear_in.weight"), (F, D))),
+                      (gm2, s["att"], gv(a_ + "final_linear.weight", (D, D))),
+                      (dqkv, s["h1"], st.span_view(a_ + "w_query.weight", a_ + "w_value.weight", (3 * D, D), grad=True))]
             ops.gemm_nt(gm, st.w(self._n(i, "w2") + ".T"), du, L.EPI_DGELU, aux=s["u"],
                         colsum=gv(self._n(i, "feed_forward.linear_in.bias")))   # s["u"] holds g' = keep*scale*gelu'(u)
-            ops.gemm_tn(gm, s["a"], gv(self._n(i, "feed_forward.linear_out.weight"), (D, F)))
+            if not batch:
+                ops.gemm_tn(*wgrads[0])
             ops.gemm_nt(du, st.w(self._n(i, "w1") + ".T"), dh_, L.EPI_BF16)
-            ops.gemm_tn(du, s["h2"], gv(self._n(i, "feed_forward.linear_in.weight"), (F, D)))
-            ops.layernorm_bwd(dh_, s["xmid"], s["mean2"], s["rstd2"], st.view(self._n(i, "layer_norm2.weight")), g, g, gm,
+            if not batch:
+                ops.gemm_tn(*wgrads[1])
+            ops.layernorm_bwd(dh_, s["xmid"], s["mean2"], s["rstd2"], st.view(self._n(i, "layer_norm2.weight")), g, g, gm2,
                               gv(self._n(i, "layer_norm2.weight")), gv(self._n(i, "layer_norm2.bias")), None,
                               self._drop(i, 0, seed, training))
             # attention
-            ops.gemm_nt(gm, st.w(self._n(i, "wo") + ".T"), dh_, L.EPI_BF16)
-            ops.gemm_tn(gm, s["att"], gv(a_ + "final_linear.weight", (D, D)))
+            ops.gemm_nt(gm2, st.w(self._n(i, "wo") + ".T"), dh_, L.EPI_BF16)
+            if not batch:
+                ops.gemm_tn(*wgrads[2])
             ops.attn_bwd(s["qkv"], s["att"], dh_, s["lse"], dqkv, delta, B, T, H, dh)
             ops.gemm_nt(dqkv, st.w(self._n(i, "wqkv") + ".T"), dh_, L.EPI_BF16)
-            ops.gemm_tn(dqkv, s["h1"], st.span_view(a_ + "w_query.weight", a_ + "w_value.weight", (3 * D, D), grad=True))
+            if batch:
+                ops.gemm_tn_batch(wgrads)      # before the LayerNorm-1 backward below overwrites gm for the next block
+            else:
+                ops.gemm_tn(*wgrads[3])
             if i > 0:
                 ops.layernorm_bwd(dh_, s["xin"], s["mean1"], s["rstd1"], st.view(self._n(i, "layer_norm1.weight")), g, g, gm,
                                   gv(self._n(i, "layer_norm1.weight")), gv(self._n(i, "layer_norm1.bias")),

@@ -259,6 +259,28 @@ def gemm_tn(A, B, Cacc, atomic=False):
     _prof_end(ev, f"gemm_tn {N1}x{N2}x{M}", 2.0 * M * N1 * N2)
 
 
+def gemm_tn_batch(jobs):
+    """For every (A, B, Cacc) of `jobs` (at most 8, all with the same row count M): Cacc[N1,N2] (fp32) += A[M,N1]^T @ B[M,N2], in
+    one launch with one shared split count and one reduce pass (vitssl_gemm_bf16_tn_batch)."""
+    if not jobs:
+        return
+    M = jobs[0][0].shape[0]
+    arr = (L.TnJob * len(jobs))()
+    flops = 0.0
+    for j, (A, B, Cacc) in enumerate(jobs):
+        if A.shape[0] != M or B.shape[0] != M:
+            raise L.VitsslError(f"gemm_tn_batch: job {j}: row counts {A.shape[0]} / {B.shape[0]} differ from {M}")
+        N1, N2 = A.shape[1], B.shape[1]
+        a, b, c = _chk(A, BF16, "A"), _chk(B, BF16, "B"), _chk(Cacc, F32, "C", (N1, N2))
+        arr[j].A, arr[j].B, arr[j].C, arr[j].N1, arr[j].N2 = a.value, b.value, c.value, N1, N2
+        flops += 2.0 * M * N1 * N2
+    wsn = int(L.lib().vitssl_gemm_tn_batch_workspace_floats(arr, len(jobs), M))
+    ws = _tn_workspace(jobs[0][0].device, wsn)
+    ev = _prof_begin()
+    call("vitssl_gemm_bf16_tn_batch", arr, len(jobs), M, C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+    _prof_end(ev, f"gemm_tn batch{len(jobs)}x{M}", flops)
+
+
 def gemm_fp8_tn(A8, B8, Cacc, alpha=None, alpha2=None):
     """Cacc[N1,N2] (fp32) += alpha * alpha2 * A8[M,N1]^T @ B8[M,N2] on e4m3 operands (weight gradient of the fp8 path)."""
     M, N1 = A8.shape
