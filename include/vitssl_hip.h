@@ -215,6 +215,19 @@ int64_t vitssl_gemm_tn_batch_workspace_floats(const vitssl_tn_job_t* jobs, int n
 int vitssl_gemm_bf16_tn_batch(const vitssl_tn_job_t* jobs, int njobs, int64_t M, float* workspace, int64_t workspace_floats,
                               void* stream);
 
+/* The same for e4m3 operands (vitssl_gemm_fp8_tn per job): C_j += alpha_j * alpha2_j * A8_j^T . B8_j.  N1, N2 % 16 == 0. */
+typedef struct {
+  const void* A8;      /* e4m3 [M, N1] */
+  const void* B8;      /* e4m3 [M, N2] */
+  float* C;            /* f32 [N1, N2], accumulated into */
+  int N1, N2;
+  const float* alpha;  /* device scalars multiplied into the product, or NULL */
+  const float* alpha2;
+} vitssl_fp8_tn_job_t;
+int64_t vitssl_gemm_fp8_tn_batch_workspace_floats(const vitssl_fp8_tn_job_t* jobs, int njobs, int64_t M);
+int vitssl_gemm_fp8_tn_batch(const vitssl_fp8_tn_job_t* jobs, int njobs, int64_t M, float* workspace, int64_t workspace_floats,
+                             void* stream);
+
 /* ---- fused multi-head self-attention (vit_core/attention.py:20-23,86-103) ----------
  * qkv  bf16 [B, N, 3, H, dh]  (the fused projection output: q | k | v per token)
  * out  bf16 [B, N, H*dh]      (heads merged, ready for final_linear)

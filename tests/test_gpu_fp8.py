@@ -536,3 +536,30 @@ def test_simmim_fp8_with_dropout_matches_oracle(fp8_operands):
     assert abs(float(loss.detach()) - float(wl.detach())) < 1e-2 * float(wl.detach())
     for k, prm in model.named_parameters():
         assert rel_l2(prm.grad, leaves[k].grad) < 6e-2, (k, rel_l2(prm.grad, leaves[k].grad))
+
+
+def test_gemm_fp8_tn_batch_matches_single_launches():
+    """vitssl_gemm_fp8_tn_batch: every job's C += alpha alpha2 A8^T B8 against one vitssl_gemm_fp8_tn per job (same e4m3 products,
+    another split of the rows: fp32 summation order only) and against an fp64 product of the same bytes."""
+    from vitssl_hip import ops
+    torch.manual_seed(5)
+    M = 2560
+    dims = [(1024, 4096), (4096, 1024), (1024, 1024), (272, 1024)]
+    jobs, singles, refs = [], [], []
+    for k, (N1, N2) in enumerate(dims):
+        A = _q8_torch(torch.randn(M, N1) * 3).to(DEV)
+        B = _q8_torch(torch.randn(M, N2) * 2).to(DEV)
+        C0 = torch.randn(N1, N2)
+        al = torch.tensor([2.0 ** -(3 + k)], device=DEV) if k != 2 else None
+        al2 = torch.tensor([2.0 ** -5], device=DEV)
+        f = (float(al) if al is not None else 1.0) * float(al2)
+        refs.append(C0.double() + f * (_f32(A).double().cpu().t() @ _f32(B).double().cpu()))
+        jobs.append((A, B, C0.clone().to(DEV), al, al2))
+        c1 = C0.clone().to(DEV)
+        ops.gemm_fp8_tn(A, B, c1, alpha=al, alpha2=al2)
+        singles.append(c1)
+    ops.gemm_fp8_tn_batch(jobs)
+    for (_, _, Cd, _, _), ref, c1 in zip(jobs, refs, singles):
+        scale = float(ref.abs().max())
+        assert float((Cd.double().cpu() - ref).abs().max()) < 2e-5 * scale
+        assert float((Cd - c1).abs().max()) < 1e-5 * scale

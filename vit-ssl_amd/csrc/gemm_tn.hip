@@ -593,28 +593,31 @@ __device__ __forceinline__ void tn8_ds_tr(tn_i32x2& dst, unsigned addr) {
   asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(IMM));
 }
 
-__global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_fp8_kernel(Tn8Params p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+// One unit of work of the e4m3 weight-gradient loop (as TnUnit; K-tiles of TN8_KM rows)
+struct Tn8Unit {
+  const unsigned char* A;
+  const unsigned char* B;
+  long long M;
+  int N1, N2;
+  int c1, c2;
+  long long ch_begin;
+  int nk;
+  float* dst;
+  int mode;               // 0 slab, 1 add into C, 2 atomic add into C, 3 compact 256 x 256 slot
+  const float* alpha;
+  const float* alpha2;
+};
+
+__device__ __forceinline__ void tn8_unit(const Tn8Unit& p, char* smem) {
   constexpr int BUF = 2 * TN_TILE_BYTES;               // one K-tile: A tile then B tile
   constexpr unsigned OOBV = 0x80000000u;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int w1 = wave >> 2, w2 = wave & 3;
 
-  const int ntiles = p.tiles1 * p.tiles2;
-  const int nwg = ntiles * p.splits;
-  const int xcd = blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7;
-  const int bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
-  const int split = bid / ntiles;
-  const int tile = bid - split * ntiles;
-  const int t1 = tile / p.tiles2, t2 = tile - t1 * p.tiles2;
-  const int c1 = t1 * TN_T, c2 = t2 * TN_T;
-
-  const long long total_chunks = (p.M + TN8_KM - 1) / TN8_KM;
-  const long long ch_begin = (long long)split * p.chunks_per_split;
-  long long ch_end = ch_begin + p.chunks_per_split;
-  if (ch_end > total_chunks) ch_end = total_chunks;
-  const int nk = ch_begin < ch_end ? (int)(ch_end - ch_begin) : 0;   // empty split: writes a zero slab
+  const int c1 = p.c1, c2 = p.c2;
+  const long long ch_begin = p.ch_begin;
+  const int nk = p.nk;
 
   __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((unsigned long long)p.M * p.N1), 0x00020000);
   __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)((unsigned long long)p.M * p.N2), 0x00020000);
@@ -704,7 +707,14 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_fp8_kernel(Tn8Params p)
   }
 
   const float al = (p.alpha ? *p.alpha : 1.0f) * (p.alpha2 ? *p.alpha2 : 1.0f);
-  float* dst = p.slabs ? p.slabs + (long long)split * p.N1 * p.N2 : p.C;
+  if (p.mode == 3) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *(f32x4*)(p.dst + (w1 * 128 + i * 16 + (lane & 15)) * TN_T + w2 * 64 + j * 16 + 4 * (lane >> 4)) = acc[i][j] * al;
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int n1 = c1 + w1 * 128 + i * 16 + (lane & 15);
@@ -713,17 +723,94 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_fp8_kernel(Tn8Params p)
     for (int j = 0; j < 4; ++j) {
       const int n2 = c2 + w2 * 64 + j * 16 + 4 * (lane >> 4);
       if (n2 >= p.N2) continue;
-      float* q = dst + (long long)n1 * p.N2 + n2;
+      float* q = p.dst + (long long)n1 * p.N2 + n2;
       const f32x4 v = acc[i][j] * al;
-      if (p.slabs) {
+      if (p.mode == 0) {
         *(f32x4*)q = v;
-      } else if (p.direct) {
+      } else if (p.mode == 1) {
         *(f32x4*)q = *(const f32x4*)q + v;
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) unsafeAtomicAdd(q + r, v[r]);
       }
     }
+  }
+}
+
+__global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_fp8_kernel(Tn8Params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int ntiles = p.tiles1 * p.tiles2;
+  const int nwg = ntiles * p.splits;
+  const int xcd = blockIdx.x & 7, qq = nwg >> 3, rr = nwg & 7;
+  const int bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
+  const int split = bid / ntiles;
+  const int tile = bid - split * ntiles;
+  const int t1 = tile / p.tiles2, t2 = tile - t1 * p.tiles2;
+  const long long total_chunks = (p.M + TN8_KM - 1) / TN8_KM;
+  const long long ch_begin = (long long)split * p.chunks_per_split;
+  long long ch_end = ch_begin + p.chunks_per_split;
+  if (ch_end > total_chunks) ch_end = total_chunks;
+  Tn8Unit u;
+  u.A = p.A;
+  u.B = p.B;
+  u.M = p.M;
+  u.N1 = p.N1;
+  u.N2 = p.N2;
+  u.c1 = t1 * TN_T;
+  u.c2 = t2 * TN_T;
+  u.ch_begin = ch_begin;
+  u.nk = ch_begin < ch_end ? (int)(ch_end - ch_begin) : 0;   // empty split: writes a zero slab
+  u.dst = p.slabs ? p.slabs + (long long)split * p.N1 * p.N2 : p.C;
+  u.mode = p.slabs ? 0 : (p.direct ? 1 : 2);
+  u.alpha = p.alpha;
+  u.alpha2 = p.alpha2;
+  tn8_unit(u, smem);
+}
+
+// several e4m3 weight gradients over the same rows in one launch (vitssl_gemm_fp8_tn_batch; see gemm_tn_batch_kernel)
+struct Tn8BatchParams {
+  TnBatchParams b;               // A / B hold the e4m3 images
+  const float* alpha[TN_MAX_JOBS];
+  const float* alpha2[TN_MAX_JOBS];
+};
+
+__global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_fp8_batch_kernel(Tn8BatchParams pp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const TnBatchParams& p = pp.b;
+  const int T = p.tile0[p.njobs];
+  const int units = T * p.splits;
+  const int G = gridDim.x;
+  const int xcd = blockIdx.x & 7, qq = G >> 3, rr = G & 7;
+  const int bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
+  const long long total_chunks = (p.M + TN8_KM - 1) / TN8_KM;
+  for (int un = bid; un < units; un += G) {
+    const int split = un / T;
+    const int gt = un - split * T;
+    int j = 0;
+#pragma unroll
+    for (int q = 1; q < TN_MAX_JOBS; ++q)
+      if (q < p.njobs && gt >= p.tile0[q]) j = q;
+    const int lt = gt - p.tile0[j];
+    const int t1 = lt / p.tiles2[j], t2 = lt - t1 * p.tiles2[j];
+    const long long ch_begin = (long long)split * p.chunks_per_split;
+    long long ch_end = ch_begin + p.chunks_per_split;
+    if (ch_end > total_chunks) ch_end = total_chunks;
+    Tn8Unit u;
+    u.A = (const unsigned char*)p.A[j];
+    u.B = (const unsigned char*)p.B[j];
+    u.M = p.M;
+    u.N1 = p.N1[j];
+    u.N2 = p.N2[j];
+    u.c1 = t1 * TN_T;
+    u.c2 = t2 * TN_T;
+    u.ch_begin = ch_begin;
+    u.nk = ch_begin < ch_end ? (int)(ch_end - ch_begin) : 0;
+    u.dst = p.slots ? p.slots + (long long)un * (TN_T * TN_T) : p.C[j];
+    u.mode = p.slots ? 3 : 1;
+    u.alpha = pp.alpha[j];
+    u.alpha2 = pp.alpha2[j];
+    tn8_unit(u, smem);
+    __syncthreads();                                   // every wave is done with the LDS before the next unit's first DMA
   }
 }
 
@@ -819,8 +906,8 @@ namespace {
 // fitted to whole-step measurements with forced split counts (VITSSL_TN_BATCH_SPLITS): ViT-B (108 tiles) 2 splits 33.27 ms,
 // 7: 33.49, 9: 33.91, 3: 35.69; ViT-S (38 tiles) 6 splits 14.35 ms, 13: 14.78, 4: 14.95, 20: 15.21, 8: 15.55.
 // 1 split = every tile has one owner: no partials.
-void tn_batch_plan(long long M, int T, int* splits, int* chunks_per_split) {
-  const long long total_chunks = (M + TN_KM - 1) / TN_KM;
+void tn_batch_plan(long long M, int T, int* splits, int* chunks_per_split, int km = TN_KM) {
+  const long long total_chunks = (M + km - 1) / km;
   const int G = vitssl_persistent_cus();
   double best = 1e30;
   int best_s = 1;
@@ -968,6 +1055,82 @@ extern "C" int vitssl_gemm_fp8_tn(const void* A8, const void* B8, float* C, int6
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, s, C, p.slabs, n4, (long long)N1 * N2, p.splits);
     VS_CHECK_LAUNCH("gemm_fp8_tn_reduce");
+  }
+  return VITSSL_OK;
+}
+
+namespace {
+int tn8_batch_fill(const vitssl_fp8_tn_job_t* jobs, int njobs, Tn8BatchParams* pp) {
+  TnBatchParams& p = pp->b;
+  int t = 0;
+  for (int j = 0; j < TN_MAX_JOBS; ++j) {
+    const bool live = j < njobs;
+    p.A[j] = live ? (const bf16_t*)jobs[j].A8 : nullptr;
+    p.B[j] = live ? (const bf16_t*)jobs[j].B8 : nullptr;
+    p.C[j] = live ? jobs[j].C : nullptr;
+    p.N1[j] = live ? jobs[j].N1 : 0;
+    p.N2[j] = live ? jobs[j].N2 : 0;
+    pp->alpha[j] = live ? jobs[j].alpha : nullptr;
+    pp->alpha2[j] = live ? jobs[j].alpha2 : nullptr;
+    p.tile0[j] = t;
+    p.tiles2[j] = live ? (jobs[j].N2 + TN_T - 1) / TN_T : 0;
+    if (live) t += ((jobs[j].N1 + TN_T - 1) / TN_T) * p.tiles2[j];
+  }
+  p.tile0[TN_MAX_JOBS] = t;
+  for (int j = njobs; j <= TN_MAX_JOBS; ++j) p.tile0[j] = t;
+  p.njobs = njobs;
+  return t;
+}
+}  // namespace
+
+extern "C" int64_t vitssl_gemm_fp8_tn_batch_workspace_floats(const vitssl_fp8_tn_job_t* jobs, int njobs, int64_t M) {
+  if (!jobs || njobs <= 0 || njobs > TN_MAX_JOBS || M <= 0) return 0;
+  Tn8BatchParams pp;
+  const int T = tn8_batch_fill(jobs, njobs, &pp);
+  int sp, cps;
+  tn_batch_plan(M, T, &sp, &cps, TN8_KM);
+  return sp > 1 ? (int64_t)sp * T * TN_T * TN_T : 0;
+}
+
+extern "C" int vitssl_gemm_fp8_tn_batch(const vitssl_fp8_tn_job_t* jobs, int njobs, int64_t M, float* workspace, int64_t workspace_floats,
+                                        void* stream) {
+  VS_CHECK_ARG(jobs && njobs > 0 && njobs <= TN_MAX_JOBS, "gemm_fp8_tn_batch: 1..%d jobs", TN_MAX_JOBS);
+  VS_CHECK_ARG(M > 0, "gemm_fp8_tn_batch: empty problem");
+  for (int j = 0; j < njobs; ++j) {
+    const vitssl_fp8_tn_job_t& q = jobs[j];
+    VS_CHECK_ARG(q.A8 && q.B8 && q.C, "gemm_fp8_tn_batch: job %d: null operand", j);
+    VS_CHECK_ARG(q.N1 > 0 && q.N2 > 0 && q.N1 % 16 == 0 && q.N2 % 16 == 0, "gemm_fp8_tn_batch: job %d: N1=%d N2=%d must be positive multiples of 16",
+                 j, q.N1, q.N2);
+    VS_CHECK_ARG((unsigned long long)M * q.N1 < (1ull << 31) && (unsigned long long)M * q.N2 < (1ull << 31),
+                 "gemm_fp8_tn_batch: job %d: operand larger than 2 GiB", j);
+  }
+  Tn8BatchParams pp;
+  TnBatchParams& p = pp.b;
+  const int T = tn8_batch_fill(jobs, njobs, &pp);
+  p.M = M;
+  tn_batch_plan(M, T, &p.splits, &p.chunks_per_split, TN8_KM);
+  const long long need = p.splits > 1 ? (long long)p.splits * T * TN_T * TN_T : 0;
+  VS_CHECK_ARG(need == 0 || (workspace && workspace_floats >= need),
+               "gemm_fp8_tn_batch: workspace of %lld floats needed (vitssl_gemm_fp8_tn_batch_workspace_floats)", need);
+  p.slots = need ? workspace : nullptr;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_fp8_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
+    if (e != hipSuccess) {
+      vitssl_set_error("gemm_fp8_tn_batch: cannot raise dynamic LDS: %s", hipGetErrorString(e));
+      return VITSSL_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const long long units = (long long)T * p.splits;
+  const long long cus = vitssl_persistent_cus();
+  const unsigned grid = (unsigned)(units < cus ? units : cus);
+  hipLaunchKernelGGL(gemm_tn_fp8_batch_kernel, dim3(grid), dim3(TN_THREADS), TN_LDS_BYTES, s, pp);
+  VS_CHECK_LAUNCH("gemm_fp8_tn_batch");
+  if (p.slots) {
+    hipLaunchKernelGGL(tn_batch_reduce_kernel, dim3((unsigned)T * 8u), dim3(256), 0, s, p);
+    VS_CHECK_LAUNCH("gemm_fp8_tn_batch_reduce");
   }
   return VITSSL_OK;
 }

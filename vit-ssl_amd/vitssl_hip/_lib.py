@@ -28,6 +28,12 @@ class TnJob(C.Structure):
     _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("N1", C.c_int), ("N2", C.c_int)]
 
 
+class Fp8TnJob(C.Structure):
+    """vitssl_fp8_tn_job_t"""
+    _fields_ = [("A8", C.c_void_p), ("B8", C.c_void_p), ("C", C.c_void_p), ("N1", C.c_int), ("N2", C.c_int),
+                ("alpha", C.c_void_p), ("alpha2", C.c_void_p)]
+
+
 class Gemm(C.Structure):
     _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("M", C.c_int64), ("N", C.c_int), ("K", C.c_int),
                 ("epilogue", C.c_int), ("bias", C.c_void_p), ("aux", C.c_void_p), ("out0", C.c_void_p),
@@ -52,6 +58,7 @@ PROTOTYPES = {
     "vitssl_gemm_bf16_nt": [C.POINTER(Gemm), _vp],
     "vitssl_gemm_bf16_tn": [_vp, _vp, _vp, _i64, _i, _i, _vp, _i64, _vp],
     "vitssl_gemm_bf16_tn_batch": [C.POINTER(TnJob), _i, _i64, _vp, _i64, _vp],
+    "vitssl_gemm_fp8_tn_batch": [C.POINTER(Fp8TnJob), _i, _i64, _vp, _i64, _vp],
     "vitssl_gemm_fp8_nt": [C.POINTER(Gemm), C.POINTER(Fp8Gemm), _vp],
     "vitssl_gemm_fp8_tn": [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _i64, _vp],
     "vitssl_quantize_fp8": [_vp, _vp, _i64, _vp],
@@ -127,6 +134,8 @@ def lib():
     l.vitssl_gemm_tn_workspace_floats.argtypes = [C.c_int64, C.c_int, C.c_int]
     l.vitssl_gemm_tn_batch_workspace_floats.restype = C.c_int64
     l.vitssl_gemm_tn_batch_workspace_floats.argtypes = [C.POINTER(TnJob), C.c_int, C.c_int64]
+    l.vitssl_gemm_fp8_tn_batch_workspace_floats.restype = C.c_int64
+    l.vitssl_gemm_fp8_tn_batch_workspace_floats.argtypes = [C.POINTER(Fp8TnJob), C.c_int, C.c_int64]
     l.vitssl_gemm_fp8_tn_workspace_floats.restype = C.c_int64
     l.vitssl_gemm_fp8_tn_workspace_floats.argtypes = [C.c_int64, C.c_int, C.c_int]
     l.vitssl_embed_bwd_workspace_floats.restype = C.c_int64

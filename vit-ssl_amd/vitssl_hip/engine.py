@@ -620,6 +620,8 @@ class EncoderStack:
         w = self.ws.get
         bw = f"bwd{M}."     # keyed by the row count: slots of different sizes (DINO local / global crops) keep their own buffers
         gm8, du8, dq8 = w(bw + "gm8", (M, D), FP8, dev), w(bw + "du8", (M, F), FP8, dev), w(bw + "dq8", (M, 3 * D), FP8, dev)
+        batch = _os.environ.get("VITSSL_TN_BATCH", "1") != "0"       # as in backward(): the block's four weight gradients in one launch
+        gm8b = w(bw + "gm8b", (M, D), FP8, dev) if batch else gm8
         dh_ = w(bw + "dh", (M, D), BF16, dev)
         delta = w(bw + "delta", (B, H, T), F32, dev)
         gv = st.gview
@@ -652,21 +654,31 @@ class EncoderStack:
             ops.gemm_fp8_nt(gm8, w2t, du, L.EPI_DGELU, alpha=a2, alpha2=inv(i, 0), aux=s["u"],
                             colsum=gv(self._n(i, "feed_forward.linear_in.bias")), out_fp8=du8, out_scale=sc(i, 1), out_amax=am(i, 1))
             settle(i, 1, du, du8)
-            ops.gemm_fp8_tn(gm8, s["a8"], gv(self._n(i, "feed_forward.linear_out.weight"), (D, F)), alpha2=inv(i, 0))
+            wgrads = [(gm8, s["a8"], gv(self._n(i, "feed_forward.linear_out.weight"), (D, F)), None, inv(i, 0)),
+                      (du8, s["h2_8"], gv(self._n(i, "feed_forward.linear_in.weight"), (F, D)), None, inv(i, 1)),
+                      (gm8b, s["att8"], gv(a_ + "final_linear.weight", (D, D)), None, inv(i, 2)),
+                      (dq8, s["h1_8"], st.span_view(a_ + "w_query.weight", a_ + "w_value.weight", (3 * D, D), grad=True), None, inv(i, 3))]
+            single = lambda j: ops.gemm_fp8_tn(wgrads[j][0], wgrads[j][1], wgrads[j][2], alpha2=wgrads[j][4])   # noqa: E731
+            if not batch:
+                single(0)
             ops.gemm_fp8_nt(du8, w1t, dh_, L.EPI_BF16, alpha=a1, alpha2=inv(i, 1))
-            ops.gemm_fp8_tn(du8, s["h2_8"], gv(self._n(i, "feed_forward.linear_in.weight"), (F, D)), alpha2=inv(i, 1))
-            ops.layernorm_bwd_fp8(dh_, s["xmid"], s["mean2"], s["rstd2"], st.view(self._n(i, "layer_norm2.weight")), g, g, gm, gm8,
+            if not batch:
+                single(1)
+            ops.layernorm_bwd_fp8(dh_, s["xmid"], s["mean2"], s["rstd2"], st.view(self._n(i, "layer_norm2.weight")), g, g, gm, gm8b,
                                   sc(i, 2), am(i, 2), gv(self._n(i, "layer_norm2.weight")), gv(self._n(i, "layer_norm2.bias")), None,
                                   self._drop(i, 0, seed, training))
-            settle(i, 2, gm, gm8)
+            settle(i, 2, gm, gm8b)
             # attention
-            ops.gemm_fp8_nt(gm8, wot, dh_, L.EPI_BF16, alpha=ao, alpha2=inv(i, 2))
-            ops.gemm_fp8_tn(gm8, s["att8"], gv(a_ + "final_linear.weight", (D, D)), alpha2=inv(i, 2))
+            ops.gemm_fp8_nt(gm8b, wot, dh_, L.EPI_BF16, alpha=ao, alpha2=inv(i, 2))
+            if not batch:
+                single(2)
             ops.attn_bwd(s["qkv"], s["att"], dh_, s["lse"], dqkv, delta, B, T, H, dh, dqkv_fp8=dq8, scale=sc(i, 3), amax=am(i, 3))
             settle(i, 3, dqkv, dq8)
             ops.gemm_fp8_nt(dq8, wqt, dh_, L.EPI_BF16, alpha=aq, alpha2=inv(i, 3))
-            ops.gemm_fp8_tn(dq8, s["h1_8"], st.span_view(a_ + "w_query.weight", a_ + "w_value.weight", (3 * D, D), grad=True),
-                            alpha2=inv(i, 3))
+            if batch:
+                ops.gemm_fp8_tn_batch(wgrads)      # before the LayerNorm-1 backward below overwrites gm8 for the next block
+            else:
+                single(3)
             if i > 0:
                 ops.layernorm_bwd_fp8(dh_, s["xin"], s["mean1"], s["rstd1"], st.view(self._n(i, "layer_norm1.weight")), g, g, gm, gm8,
                                       sc(i - 1, 0), am(i - 1, 0), gv(self._n(i, "layer_norm1.weight")), gv(self._n(i, "layer_norm1.bias")),

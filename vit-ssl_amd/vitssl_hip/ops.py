@@ -101,6 +101,29 @@ def _scalar(t, name):
     return _chk(t, F32, name)
 
 
+def gemm_fp8_tn_batch(jobs):
+    """For every (A8, B8, Cacc, alpha, alpha2) of `jobs` (at most 8, same row count M): Cacc += alpha * alpha2 * A8^T @ B8 on e4m3
+    operands, in one launch (vitssl_gemm_fp8_tn_batch)."""
+    if not jobs:
+        return
+    M = jobs[0][0].shape[0]
+    arr = (L.Fp8TnJob * len(jobs))()
+    flops = 0.0
+    for j, (A8, B8, Cacc, alpha, alpha2) in enumerate(jobs):
+        if A8.shape[0] != M or B8.shape[0] != M:
+            raise L.VitsslError(f"gemm_fp8_tn_batch: job {j}: row counts {A8.shape[0]} / {B8.shape[0]} differ from {M}")
+        N1, N2 = A8.shape[1], B8.shape[1]
+        a, b, c = _chk(A8, FP8, "A8"), _chk(B8, FP8, "B8"), _chk(Cacc, F32, "C", (N1, N2))
+        arr[j].A8, arr[j].B8, arr[j].C, arr[j].N1, arr[j].N2 = a.value, b.value, c.value, N1, N2
+        arr[j].alpha, arr[j].alpha2 = _scalar(alpha, "alpha").value, _scalar(alpha2, "alpha2").value
+        flops += 2.0 * M * N1 * N2
+    wsn = int(L.lib().vitssl_gemm_fp8_tn_batch_workspace_floats(arr, len(jobs), M))
+    ws = _tn_workspace(jobs[0][0].device, wsn)
+    ev = _prof_begin()
+    call("vitssl_gemm_fp8_tn_batch", arr, len(jobs), M, C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+    _prof_end(ev, f"gemm_fp8_tn batch{len(jobs)}x{M}", flops)
+
+
 def quantize_fp8(x, y8, scale=None, amax=None):
     """y8 = e4m3(clamp(x * scale, +-448)) of a bf16 tensor; `scale` / `amax` are optional 1-element device tensors
     (amax receives max(amax, max|x|))."""
