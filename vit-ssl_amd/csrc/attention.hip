@@ -45,6 +45,10 @@ __device__ unsigned long long* g_attn_stamps = nullptr;   // [workgroup][4] x 10
 // 276 us, in phase 242 us -- the second barrier per step costs more than the MFMA / VALU overlap between SIMD partners
 // returns; kept as an A/B build.  (Moving dV / dK behind the step's barrier, which both forms share, was worth 253 -> 242 us:
 // the dS columns are published before the 16 MFMAs + 32 transposed reads instead of after them.)
+// 1: the pipelined backward keeps its K^T fragments for the dQ contraction in registers for the whole item (223 -> 218 us at B256 H12 N196; 248 VGPRs)
+#ifndef ATTN_BWD_KT_REGS
+#define ATTN_BWD_KT_REGS 1
+#endif
 #ifndef ATTN_BWD_STAGGER
 #define ATTN_BWD_STAGGER 0
 #endif
@@ -1266,13 +1270,26 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(const bf16_t* __rest
                          (unsigned)(tile_off(4 * g + tq, 2 * dt_w + (tpp >> 1)) - tile_off(4 * g + tq, (tpp >> 1)));
 
   // dQ^T[d][q] = sum_key K[key][d] dS[q][key] for this wave's tile of step qs, from exchange image sx
+#if ATTN_BWD_KT_REGS
+  // this wave's K^T fragments (16 head dimensions x all keys) are the same in every step: read once, 4 NS registers
+  s16x4 klo[NS], khi[NS];
+  auto load_kt = [&]() {
+    static_for<NS>([&](auto st_c) {
+      constexpr int st = decltype(st_c)::value;
+      ds_tr16<4096 * st>(klo[st], kaddr);
+      ds_tr16<4096 * st + 2048>(khi[st], kaddr);
+    });
+  };
+#endif
   auto dq_tile = [&](const char* sx, int qs) {
+#if !ATTN_BWD_KT_REGS
     s16x4 klo[NS], khi[NS];
     static_for<NS>([&](auto st_c) {
       constexpr int st = decltype(st_c)::value;
       ds_tr16<4096 * st>(klo[st], kaddr);
       ds_tr16<4096 * st + 2048>(khi[st], kaddr);
     });
+#endif
     const char* rowp = sx + (16 * qt_w + li) * SROW + 8 * g;
     u32x2 dlo[NS], dhi[NS];
 #pragma unroll
@@ -1301,6 +1318,9 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(const bf16_t* __rest
     }
   };
 
+#if ATTN_BWD_KT_REGS
+  load_kt();                                       // (the K tile landed with the prologue's wait; the step's lgkmcnt(0) covers the reads)
+#endif
 #pragma unroll 1
   for (int qs = 0; qs < NS; ++qs) {
     char* sx = Sx + (qs & 1) * 32 * SROW;
