@@ -554,7 +554,15 @@ __global__ __launch_bounds__(256) void tn_batch_reduce_kernel(TnBatchParams p) {
     if (n1 >= p.N1[j]) break;
     float* q = p.C[j] + (long long)n1 * p.N2[j] + n2;
     f32x4 a = *(const f32x4*)q;
-    for (int s = 0; s < p.splits; ++s) a += *(const f32x4*)(p.slots + ((long long)s * T + gt) * (TN_T * TN_T) + row * TN_T + col);
+    const float* sl = p.slots + (long long)gt * (TN_T * TN_T) + row * TN_T + col;
+    const long long sstride = (long long)T * (TN_T * TN_T);
+    int s = 0;
+    for (; s + 4 <= p.splits; s += 4) {               // four independent loads in flight per row
+      const f32x4 v0 = *(const f32x4*)(sl + (s + 0) * sstride), v1 = *(const f32x4*)(sl + (s + 1) * sstride);
+      const f32x4 v2 = *(const f32x4*)(sl + (s + 2) * sstride), v3 = *(const f32x4*)(sl + (s + 3) * sstride);
+      a += (v0 + v1) + (v2 + v3);
+    }
+    for (; s < p.splits; ++s) a += *(const f32x4*)(sl + s * sstride);
     *(f32x4*)q = a;
   }
 }
