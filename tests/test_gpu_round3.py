@@ -125,3 +125,24 @@ def test_gemm_tn_batch_matches_single_launches(M, dims):
         assert float((Cd.double().cpu() - ref2).abs().max()) < 3e-5 * float(ref2.abs().max())
     with pytest.raises(Exception, match="row counts"):
         ops.gemm_tn_batch([jobs[0], (jobs[0][0][:-8], jobs[0][1][:-8], jobs[0][2])])
+
+
+def test_gemm_tn_batch_with_helper_workgroups_at_full_size():
+    """At M = 50 176 the ViT-B list (108 tiles x 2 splits = 216 units) leaves CUs idle and the planner hands the last rows of every
+    tile to the idle workgroups (three partials per tile: csrc/gemm_tn.hip, tn_batch_plan).  Same products as one launch per
+    gradient: only the fp32 summation order differs."""
+    from vitssl_hip import ops
+    M = 50176
+    g = torch.Generator(device=DEV).manual_seed(11)
+    jobs, singles = [], []
+    for (N1, N2) in [(768, 3072), (3072, 768), (768, 768), (2304, 768)]:
+        A = (torch.randn(M, N1, generator=g, device=DEV) * 0.5).to(torch.bfloat16)
+        B = (torch.randn(M, N2, generator=g, device=DEV) * 0.5).to(torch.bfloat16)
+        C0 = torch.randn(N1, N2, generator=g, device=DEV)
+        jobs.append((A, B, C0.clone()))
+        c1 = C0.clone()
+        ops.gemm_tn(A, B, c1)
+        singles.append(c1)
+    ops.gemm_tn_batch(jobs)
+    for (_, _, Cd), c1 in zip(jobs, singles):
+        assert float((Cd - c1).abs().max()) < 2e-5 * float(c1.abs().max())

@@ -494,39 +494,73 @@ struct TnBatchParams {
   int njobs;
   long long M;
   int splits, chunks_per_split;
-  float* slots;                  // [splits * T][256][256] partial tiles (unit-major), or nullptr when splits == 1
+  int rem_chunks;                // > 0: one round; the last rem_chunks K-tiles of EVERY tile are taken by the workgroups beyond T x splits
+                                 // (round-robin over the tiles) and land in the slots of "split" number `splits`
+  float* slots;                  // [(splits + (rem_chunks > 0)) * T][256][256] partial tiles, or nullptr when every tile has one owner
 };
+
+// Units of the batch kernels.  Without a remainder range: unit u = split * T + tile, workgroup w takes u = w, w + G, ...
+// With one (p.rem_chunks > 0; then T * splits <= G): workgroup w < T * splits takes unit w alone, the others share the
+// remainder units (K-tiles [splits * chunks_per_split, total) of tile t, slot splits * T + t) round-robin.
+struct TnBatchWalk {
+  int first, step, end;          // unit indices first, first + step, ... < end
+};
+__device__ __forceinline__ TnBatchWalk tn_batch_walk(const TnBatchParams& p, int bid, int G) {
+  const int T = p.tile0[p.njobs];
+  const int mainu = T * p.splits;
+  TnBatchWalk w;
+  if (p.rem_chunks > 0) {
+    if (bid < mainu) {
+      w.first = bid;
+      w.step = mainu + T;
+      w.end = mainu;
+    } else {
+      w.first = mainu + (bid - mainu);
+      w.step = G - mainu;
+      w.end = mainu + T;
+    }
+  } else {
+    w.first = bid;
+    w.step = G;
+    w.end = mainu;
+  }
+  return w;
+}
+// (job, tile origin, K range) of unit un
+__device__ __forceinline__ void tn_batch_unit(const TnBatchParams& p, int un, int km, int& j, int& c1, int& c2, long long& ch_begin, int& nk) {
+  const int T = p.tile0[p.njobs];
+  const int split = un / T;
+  const int gt = un - split * T;
+  j = 0;
+#pragma unroll
+  for (int q = 1; q < TN_MAX_JOBS; ++q)
+    if (q < p.njobs && gt >= p.tile0[q]) j = q;
+  const int lt = gt - p.tile0[j];
+  const int t1 = lt / p.tiles2[j], t2 = lt - t1 * p.tiles2[j];
+  c1 = t1 * TN_T;
+  c2 = t2 * TN_T;
+  const long long total_chunks = (p.M + km - 1) / km;
+  ch_begin = (long long)split * p.chunks_per_split;
+  long long ch_end = split < p.splits ? ch_begin + p.chunks_per_split : total_chunks;     // "split" == splits: the remainder range
+  if (ch_end > total_chunks) ch_end = total_chunks;
+  nk = ch_begin < ch_end ? (int)(ch_end - ch_begin) : 0;
+}
 
 __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_batch_kernel(TnBatchParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int T = p.tile0[p.njobs];
-  const int units = T * p.splits;
   const int G = gridDim.x;
   const int xcd = blockIdx.x & 7, qq = G >> 3, rr = G & 7;
   const int bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
-  const long long total_chunks = (p.M + TN_KM - 1) / TN_KM;
-  for (int un = bid; un < units; un += G) {
-    const int split = un / T;
-    const int gt = un - split * T;
-    int j = 0;
-#pragma unroll
-    for (int q = 1; q < TN_MAX_JOBS; ++q)
-      if (q < p.njobs && gt >= p.tile0[q]) j = q;
-    const int lt = gt - p.tile0[j];
-    const int t1 = lt / p.tiles2[j], t2 = lt - t1 * p.tiles2[j];
-    const long long ch_begin = (long long)split * p.chunks_per_split;
-    long long ch_end = ch_begin + p.chunks_per_split;
-    if (ch_end > total_chunks) ch_end = total_chunks;
+  const TnBatchWalk w = tn_batch_walk(p, bid, G);
+  for (int un = w.first; un < w.end; un += w.step) {
     TnUnit u;
+    int j;
+    tn_batch_unit(p, un, TN_KM, j, u.c1, u.c2, u.ch_begin, u.nk);
     u.A = p.A[j];
     u.B = p.B[j];
     u.M = p.M;
     u.N1 = p.N1[j];
     u.N2 = p.N2[j];
-    u.c1 = t1 * TN_T;
-    u.c2 = t2 * TN_T;
-    u.ch_begin = ch_begin;
-    u.nk = ch_begin < ch_end ? (int)(ch_end - ch_begin) : 0;
     u.dst = p.slots ? p.slots + (long long)un * (TN_T * TN_T) : p.C[j];
     u.mode = p.slots ? 3 : 1;
     u.stamp_wg = -1;
@@ -556,13 +590,14 @@ __global__ __launch_bounds__(256) void tn_batch_reduce_kernel(TnBatchParams p) {
     f32x4 a = *(const f32x4*)q;
     const float* sl = p.slots + (long long)gt * (TN_T * TN_T) + row * TN_T + col;
     const long long sstride = (long long)T * (TN_T * TN_T);
+    const int nsl = p.splits + (p.rem_chunks > 0 ? 1 : 0);
     int s = 0;
-    for (; s + 4 <= p.splits; s += 4) {               // four independent loads in flight per row
+    for (; s + 4 <= nsl; s += 4) {                    // four independent loads in flight per row
       const f32x4 v0 = *(const f32x4*)(sl + (s + 0) * sstride), v1 = *(const f32x4*)(sl + (s + 1) * sstride);
       const f32x4 v2 = *(const f32x4*)(sl + (s + 2) * sstride), v3 = *(const f32x4*)(sl + (s + 3) * sstride);
       a += (v0 + v1) + (v2 + v3);
     }
-    for (; s < p.splits; ++s) a += *(const f32x4*)(sl + s * sstride);
+    for (; s < nsl; ++s) a += *(const f32x4*)(sl + s * sstride);
     *(f32x4*)q = a;
   }
 }
@@ -785,34 +820,19 @@ struct Tn8BatchParams {
 __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_fp8_batch_kernel(Tn8BatchParams pp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const TnBatchParams& p = pp.b;
-  const int T = p.tile0[p.njobs];
-  const int units = T * p.splits;
   const int G = gridDim.x;
   const int xcd = blockIdx.x & 7, qq = G >> 3, rr = G & 7;
   const int bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
-  const long long total_chunks = (p.M + TN8_KM - 1) / TN8_KM;
-  for (int un = bid; un < units; un += G) {
-    const int split = un / T;
-    const int gt = un - split * T;
-    int j = 0;
-#pragma unroll
-    for (int q = 1; q < TN_MAX_JOBS; ++q)
-      if (q < p.njobs && gt >= p.tile0[q]) j = q;
-    const int lt = gt - p.tile0[j];
-    const int t1 = lt / p.tiles2[j], t2 = lt - t1 * p.tiles2[j];
-    const long long ch_begin = (long long)split * p.chunks_per_split;
-    long long ch_end = ch_begin + p.chunks_per_split;
-    if (ch_end > total_chunks) ch_end = total_chunks;
+  const TnBatchWalk w = tn_batch_walk(p, bid, G);
+  for (int un = w.first; un < w.end; un += w.step) {
     Tn8Unit u;
+    int j;
+    tn_batch_unit(p, un, TN8_KM, j, u.c1, u.c2, u.ch_begin, u.nk);
     u.A = (const unsigned char*)p.A[j];
     u.B = (const unsigned char*)p.B[j];
     u.M = p.M;
     u.N1 = p.N1[j];
     u.N2 = p.N2[j];
-    u.c1 = t1 * TN_T;
-    u.c2 = t2 * TN_T;
-    u.ch_begin = ch_begin;
-    u.nk = ch_begin < ch_end ? (int)(ch_end - ch_begin) : 0;
     u.dst = p.slots ? p.slots + (long long)un * (TN_T * TN_T) : p.C[j];
     u.mode = p.slots ? 3 : 1;
     u.alpha = pp.alpha[j];
@@ -914,9 +934,10 @@ namespace {
 // fitted to whole-step measurements with forced split counts (VITSSL_TN_BATCH_SPLITS): ViT-B (108 tiles) 2 splits 33.27 ms,
 // 7: 33.49, 9: 33.91, 3: 35.69; ViT-S (38 tiles) 6 splits 14.35 ms, 13: 14.78, 4: 14.95, 20: 15.21, 8: 15.55.
 // 1 split = every tile has one owner: no partials.
-void tn_batch_plan(long long M, int T, int* splits, int* chunks_per_split, int km = TN_KM) {
+void tn_batch_plan(long long M, int T, int* splits, int* chunks_per_split, int* rem_chunks, int km = TN_KM) {
   const long long total_chunks = (M + km - 1) / km;
   const int G = vitssl_persistent_cus();
+  const double c_kt = 1.46, c_unit = 9.0, c_part = 0.15;        // us per K-tile of a unit, per unit, per partial tile (see above)
   double best = 1e30;
   int best_s = 1;
   const long long smax = total_chunks < 64 ? total_chunks : 64;
@@ -926,7 +947,7 @@ void tn_batch_plan(long long M, int T, int* splits, int* chunks_per_split, int k
     if (s_eff != sp) continue;                                  // same partition as a smaller count
     const long long units = (long long)T * sp;
     const long long rounds = (units + G - 1) / G;
-    const double cost = (double)rounds * ((double)cps * 1.46 + 9.0) + (sp > 1 ? (double)units * 0.15 : 0.0);
+    const double cost = (double)rounds * ((double)cps * c_kt + c_unit) + (sp > 1 ? (double)units * c_part : 0.0);
     if (cost < best) {
       best = cost;
       best_s = (int)sp;
@@ -940,6 +961,36 @@ void tn_batch_plan(long long M, int T, int* splits, int* chunks_per_split, int k
   if (forced > 0 && forced <= total_chunks) best_s = forced;
   *chunks_per_split = (int)((total_chunks + best_s - 1) / best_s);
   *splits = (int)((total_chunks + *chunks_per_split - 1) / *chunks_per_split);
+  *rem_chunks = 0;
+  // One round with idle CUs (ViT-B: 108 tiles x 2 splits = 216 of 256): the R idle workgroups take the LAST part of every tile's
+  // rows, ceil(T / R) tiles each, and the main units shrink until both kinds finish together:
+  //   L c_kt + c_unit = n_r ((total - S L) c_rem + c_unit).
+  // c_rem > c_kt: the few helper workgroups of an XCD work on different tiles and share little in L2.  Measured (whole step, same
+  // box, alternating; helpers sized with c_rem = c_kt): ViT-B 32.90 -> 32.67 ms, but ViT-S 14.17 -> 14.24 and DINO 39.9 -> 40.2
+  // where the model promised 7 %: with c_rem = 2.2 us and a 5 % threshold only the ViT-B-like lists use helpers.
+  // VITSSL_TN_BATCH_REM=0 turns them off.
+  static int use_rem = -1;
+  if (use_rem < 0) {
+    const char* e = getenv("VITSSL_TN_BATCH_REM");
+    use_rem = e ? atoi(e) : 1;
+  }
+  const long long mainu = (long long)T * *splits;
+  const long long R = G - mainu;
+  if (use_rem && mainu <= G && R >= 8) {
+    const double c_rem = 2.2;
+    const long long S = *splits;
+    const double nr = (double)((T + R - 1) / R);
+    const double L = (nr * ((double)total_chunks * c_rem + c_unit) - c_unit) / (c_kt + nr * (double)S * c_rem);
+    long long Li = (long long)(L + 0.999);
+    const long long rem = total_chunks - S * Li;
+    const double t_main = (double)Li * c_kt + c_unit, t_rem = nr * ((double)rem * c_rem + c_unit);
+    const double t_old = (double)*chunks_per_split * c_kt + c_unit;
+    const double tax = (double)T * c_part * (S == 1 ? 2.0 : 1.0);             // T more partials (with one split there were none)
+    if (rem >= 4 && Li >= 4 && (t_main > t_rem ? t_main : t_rem) + tax < 0.95 * t_old) {
+      *chunks_per_split = (int)Li;
+      *rem_chunks = (int)rem;
+    }
+  }
 }
 int tn_batch_tiles(const vitssl_tn_job_t* jobs, int njobs, TnBatchParams* p) {
   int t = 0;
@@ -957,9 +1008,9 @@ extern "C" int64_t vitssl_gemm_tn_batch_workspace_floats(const vitssl_tn_job_t* 
   if (!jobs || njobs <= 0 || njobs > TN_MAX_JOBS || M <= 0) return 0;
   TnBatchParams p;
   const int T = tn_batch_tiles(jobs, njobs, &p);
-  int sp, cps;
-  tn_batch_plan(M, T, &sp, &cps);
-  return sp > 1 ? (int64_t)sp * T * TN_T * TN_T : 0;
+  int sp, cps, rem;
+  tn_batch_plan(M, T, &sp, &cps, &rem);
+  return (sp > 1 || rem > 0) ? (int64_t)(sp + (rem > 0)) * T * TN_T * TN_T : 0;
 }
 
 extern "C" int vitssl_gemm_bf16_tn_batch(const vitssl_tn_job_t* jobs, int njobs, int64_t M, float* workspace, int64_t workspace_floats,
@@ -989,8 +1040,8 @@ extern "C" int vitssl_gemm_bf16_tn_batch(const vitssl_tn_job_t* jobs, int njobs,
   for (int j = njobs + 1; j <= TN_MAX_JOBS; ++j) p.tile0[j] = T;
   p.njobs = njobs;
   p.M = M;
-  tn_batch_plan(M, T, &p.splits, &p.chunks_per_split);
-  const long long need = p.splits > 1 ? (long long)p.splits * T * TN_T * TN_T : 0;
+  tn_batch_plan(M, T, &p.splits, &p.chunks_per_split, &p.rem_chunks);
+  const long long need = (p.splits > 1 || p.rem_chunks > 0) ? (long long)(p.splits + (p.rem_chunks > 0)) * T * TN_T * TN_T : 0;
   VS_CHECK_ARG(need == 0 || (workspace && workspace_floats >= need), "gemm_tn_batch: workspace of %lld floats needed (vitssl_gemm_tn_batch_workspace_floats)",
                need);
   p.slots = need ? workspace : nullptr;
@@ -1006,7 +1057,7 @@ extern "C" int vitssl_gemm_bf16_tn_batch(const vitssl_tn_job_t* jobs, int njobs,
   hipStream_t s = (hipStream_t)stream;
   const long long units = (long long)T * p.splits;
   const long long cus = vitssl_persistent_cus();
-  const unsigned grid = (unsigned)(units < cus ? units : cus);
+  const unsigned grid = (unsigned)((units < cus && p.rem_chunks == 0) ? units : cus);      // (with a remainder range every CU has work)
   hipLaunchKernelGGL(gemm_tn_batch_kernel, dim3(grid), dim3(TN_THREADS), TN_LDS_BYTES, s, p);
   VS_CHECK_LAUNCH("gemm_tn_batch");
   if (p.slots) {
@@ -1095,9 +1146,9 @@ extern "C" int64_t vitssl_gemm_fp8_tn_batch_workspace_floats(const vitssl_fp8_tn
   if (!jobs || njobs <= 0 || njobs > TN_MAX_JOBS || M <= 0) return 0;
   Tn8BatchParams pp;
   const int T = tn8_batch_fill(jobs, njobs, &pp);
-  int sp, cps;
-  tn_batch_plan(M, T, &sp, &cps, TN8_KM);
-  return sp > 1 ? (int64_t)sp * T * TN_T * TN_T : 0;
+  int sp, cps, rem;
+  tn_batch_plan(M, T, &sp, &cps, &rem, TN8_KM);
+  return (sp > 1 || rem > 0) ? (int64_t)(sp + (rem > 0)) * T * TN_T * TN_T : 0;
 }
 
 extern "C" int vitssl_gemm_fp8_tn_batch(const vitssl_fp8_tn_job_t* jobs, int njobs, int64_t M, float* workspace, int64_t workspace_floats,
@@ -1116,8 +1167,8 @@ extern "C" int vitssl_gemm_fp8_tn_batch(const vitssl_fp8_tn_job_t* jobs, int njo
   TnBatchParams& p = pp.b;
   const int T = tn8_batch_fill(jobs, njobs, &pp);
   p.M = M;
-  tn_batch_plan(M, T, &p.splits, &p.chunks_per_split, TN8_KM);
-  const long long need = p.splits > 1 ? (long long)p.splits * T * TN_T * TN_T : 0;
+  tn_batch_plan(M, T, &p.splits, &p.chunks_per_split, &p.rem_chunks, TN8_KM);
+  const long long need = (p.splits > 1 || p.rem_chunks > 0) ? (long long)(p.splits + (p.rem_chunks > 0)) * T * TN_T * TN_T : 0;
   VS_CHECK_ARG(need == 0 || (workspace && workspace_floats >= need),
                "gemm_fp8_tn_batch: workspace of %lld floats needed (vitssl_gemm_fp8_tn_batch_workspace_floats)", need);
   p.slots = need ? workspace : nullptr;
@@ -1133,7 +1184,7 @@ extern "C" int vitssl_gemm_fp8_tn_batch(const vitssl_fp8_tn_job_t* jobs, int njo
   hipStream_t s = (hipStream_t)stream;
   const long long units = (long long)T * p.splits;
   const long long cus = vitssl_persistent_cus();
-  const unsigned grid = (unsigned)(units < cus ? units : cus);
+  const unsigned grid = (unsigned)((units < cus && p.rem_chunks == 0) ? units : cus);
   hipLaunchKernelGGL(gemm_tn_fp8_batch_kernel, dim3(grid), dim3(TN_THREADS), TN_LDS_BYTES, s, pp);
   VS_CHECK_LAUNCH("gemm_fp8_tn_batch");
   if (p.slots) {
