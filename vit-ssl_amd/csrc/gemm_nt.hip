@@ -245,9 +245,12 @@ __device__ __forceinline__ bool glut_out_of_range(unsigned r01, unsigned r23) {
 }
 // plain LDS loads (the compiler counts them): checked in the .s that no vmcnt wait is attached to them -- the operand DMA in
 // flight during the epilogue writes other LDS bytes, but hipcc cannot always prove that (cdna guide, "three .s-level traps")
+// (Addressed as a raw LDS offset: through the `smem` symbol hipcc emits one `v_add_u32 v, 0, v` per lookup that it does not fold.
+// The kernel has no static LDS, so its dynamic LDS starts at offset 0; the kernel traps at entry if that ever stops being true.)
 template <int OFF>
 __device__ __forceinline__ unsigned glut_read(const char* smem, unsigned a) {
-  return *(const unsigned*)(smem + OFF + a);
+  (void)smem;
+  return *(const __attribute__((address_space(3))) unsigned*)(unsigned long long)(a + (unsigned)OFF);
 }
 
 // Fused epilogue of one 128x64 wave tile (shared by both main-loop variants).
@@ -1256,6 +1259,7 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_nt_pp_kernel(NtParams p)
   stage_a(c1, 1, IC<0>{});
   Cur c2 = cur_next(c1);
   if constexpr (USE_GLUT) {
+    if ((unsigned)(unsigned long long)LDS_PTR(smem) != 0u) __builtin_trap();      // glut_read addresses the table by raw LDS offsets
     // fill the table while the first K-tiles are in flight: entry (magnitude index, sign) = the two bf16 results for that
     // bf16 input, from the SAME function the arithmetic path evaluates.  Every wave passes the K loop's barriers before
     // the first epilogue reads it.
