@@ -103,6 +103,7 @@ def main():
         cs = torch.zeros(N, device=DEV)
         cases = {
             "bf16": (L.EPI_BF16, dict(out0=o16)),
+            "bf16+bias": (L.EPI_BF16, dict(out0=o16, bias=bias)),
             "f32": (L.EPI_F32, dict(out0=o32, bias=bias)),
             "resid+drop": (L.EPI_RESID, dict(out0=o32, aux=res, bias=bias, drop=True)),
             "resid": (L.EPI_RESID, dict(out0=o32, aux=res, bias=bias)),
