@@ -79,6 +79,10 @@
 #define NT_LDS_T 1
 #endif
 // start-up stagger window of the ping-pong kernel in tile times (VITSSL_NT_STAGGER overrides)
+// 1: the K-tile position of the ping-pong loop's operand DMA lives in the buffer descriptor instead of the lanes' offsets
+#ifndef NT_DESC_WINDOW
+#define NT_DESC_WINDOW 1
+#endif
 // 1: s_setprio 1 around the MFMA clusters of the ping-pong loop.  Round 2 measured it neutral; with the leaner loops of round 3 it
 // costs 0.5-1.5 % on 15 of 16 shape x epilogue pairs (interleaved A/B, profiles/r03_tls_ab.txt): 8 more scalar instructions per
 // K-tile in loops whose LOAD parts are bound by issue slots (see gemm_tn.hip).  Default off.
@@ -1126,19 +1130,28 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_nt_pp_kernel(NtParams p)
   auto stage_a = [&](const Cur& c, int bufsel, auto h_c) {
     constexpr int h = decltype(h_c)::value;
     if (NT_LOOP_ABLATE == 1 && bufsel >= 0) return;
+    // The K-tile's position goes into the DESCRIPTOR (scalar arithmetic: window = operand bytes from (tile row 0, k0) on; an ended
+    // stream gets an empty window -> zero fill, no traffic), not into the lanes' offsets: the LOAD parts of this loop share their SIMD
+    // with the partner wave's MFMA cluster and vector-ALU instructions there cost issue slots (csrc/gemm_tn.hip).
+    __amdgpu_buffer_rsrc_t rs = NT_DESC_WINDOW ? __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A + c.a), 0,
+                                                                                    c.a == OOBV ? 0 : (int)(a_bytes - c.a), 0x00020000)
+                                               : rsA;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const bool live = ldsA[h][e] != DUMMY;
-      // (an ended stream has c.a = OOBV: the sum is out of range for every live slot -> zero fill)
-      dma16_to_lds(rsA, smem + (live ? bufsel * BUF : 0) + ldsA[h][e], voffA[h][e] + c.a);
+      // (an ended stream has c.a = OOBV: out of range for every live slot -> zero fill)
+      dma16_to_lds(rs, smem + (live ? bufsel * BUF : 0) + ldsA[h][e], NT_DESC_WINDOW ? voffA[h][e] : voffA[h][e] + c.a);
     }
   };
   auto stage_b = [&](const Cur& c, int bufsel, auto h_c) {
     constexpr int h = decltype(h_c)::value;
     if (NT_LOOP_ABLATE == 1 && bufsel >= 0) return;
+    __amdgpu_buffer_rsrc_t rs = NT_DESC_WINDOW ? __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.B + c.b), 0,
+                                                                                    c.b == OOBV ? 0 : (int)(b_bytes - c.b), 0x00020000)
+                                               : rsB;
 #pragma unroll
     for (int e = 0; e < 2; ++e)
-      dma16_to_lds(rsB, smem + bufsel * BUF + ldsB[h][e], voffB[h][e] + c.b);
+      dma16_to_lds(rs, smem + bufsel * BUF + ldsB[h][e], NT_DESC_WINDOW ? voffB[h][e] : voffB[h][e] + c.b);
   };
 
   // ---- fragment addressing (as in gemm_nt_kernel)
