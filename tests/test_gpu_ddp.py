@@ -227,3 +227,48 @@ def test_bench_two_rank_path_reports_its_collectives(tmp_path, model, dtype):
     assert dp["world_size"] == 2 and dp["allreduce_of_ones"] == 2.0 and dp["backend"] == "gloo"
     assert dp["buckets_per_step"] >= 1 and dp["reduced_bytes_per_step"] >= 0.99 * dp["grad_bytes"] - 64 * 4 * 200
     assert "exposed_comm_ms" in dp and d["roofline"]["hbm"]["ln_fwd"]["launches"] > 0
+
+
+def _entry_worker(rank, world, port, out_dir):
+    """The reference's entry path under torch.distributed.run (train.py:107-128): setup_device() -> build_model ->
+    trainer -> fit, with nothing else creating the process group.  Rehearsed on one card: VITSSL_SHARE_GPU binds both
+    ranks to cuda:0, VITSSL_DIST_BACKEND=gloo (RCCL refuses two ranks on one device)."""
+    for p in (ROOT, os.path.join(ROOT, "vit-ssl_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      VITSSL_DIST_BACKEND="gloo", VITSSL_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from utils import build_model, setup_device
+    from utils.trainers import SimMIMTrainer
+    from vitssl_hip.optim import FusedAdamW
+    device = setup_device()
+    try:
+        assert device == torch.device("cuda:0") and dist.is_initialized() and dist.get_world_size() == world
+        cfg = {"training": {"type": "simmim", "num_epochs": 1, "warmup_epochs": 1, "warmup_initial_learning_rate": 1e-6,
+                            "warmup_final_learning_rate": 1e-3, "criterion": {"name": "L1Loss", "params": {"reduction": "mean"}},
+                            "optimizer": {"name": "AdamW", "params": {"lr": 1e-3, "weight_decay": 1e-3}},
+                            "lr_scheduler": {"main": {"name": "CosineAnnealingLR", "params": {"eta_min": 1e-6}}, "warmup": {"params": {}}}},
+               "eval": {}, "data": {"img_size": 32},
+               "model": {"in_channels": 3, "patch_size": 8, "embed_dim": 128, "num_blocks": 2, "num_heads": 2, "mlp_dim": 192,
+                         "dropout": 0.1, "mask_ratio": 0.6}}
+        torch.manual_seed(50 + rank)                    # per-rank init, per-rank data, per-rank masks / dropout
+        model = build_model(cfg).to(device)
+        data = [torch.rand(8, 3, 32, 32) for _ in range(3)]
+        tr = SimMIMTrainer(model, os.path.join(out_dir, f"r{rank}"), cfg, data, data[:1], device)
+        assert tr.world == world and tr.reducer is not None and isinstance(tr.optimizer, FusedAdamW) and tr._fused_ok()
+        store = model.flat_store()
+        w0 = store.flat.clone()
+        tr.fit(1)
+        torch.cuda.synchronize()
+        flats = [torch.empty_like(store.flat) for _ in range(world)]
+        dist.all_gather(flats, store.flat)
+        assert torch.equal(flats[0], flats[1]) and not torch.equal(flats[0], w0)
+        assert len(tr.reducer.launched) >= 1
+        open(os.path.join(out_dir, f"entry_ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_entry_point_path_is_data_parallel(tmp_path):
+    world = 2
+    mp.spawn(_entry_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"entry_ok{r}").exists() for r in range(world))

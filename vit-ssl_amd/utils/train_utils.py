@@ -81,17 +81,55 @@ def get_transforms(config):
     return out
 
 
+def init_data_parallel(device=None, backend=None):
+    """Join the data-parallel job `torch.distributed.run` started, once: when WORLD_SIZE > 1 and no process group exists yet,
+    size RCCL to the CUs the persistent GEMM grids leave free (`engine.configure_collectives`, must precede the
+    communicator) and call `init_process_group` (backend "nccl" = RCCL, bound to `device`; VITSSL_DIST_BACKEND overrides,
+    e.g. "gloo" for a rehearsal on CPU or on one GPU).  An already initialised group is left alone.  Returns the world size.
+    The reference has no multi-GPU path (train.py:107 only calls setup_device()); this is the "DDP added" of SURVEY 8(b):
+    with it `BaseTrainer` finds an initialised group and builds its GradReducer."""
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1") or 1)
+    if not dist.is_available():
+        if world > 1:
+            raise RuntimeError(f"WORLD_SIZE={world} but this torch build has no torch.distributed")
+        return 1
+    if dist.is_initialized():
+        return dist.get_world_size()
+    if world <= 1:
+        return 1
+    backend = backend or os.environ.get("VITSSL_DIST_BACKEND", "nccl")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in os.environ or "RANK" not in os.environ:
+        raise RuntimeError(f"WORLD_SIZE={world} but RANK / MASTER_PORT are not set: launch with "
+                           "`python -m torch.distributed.run --nproc-per-node N train.py ...` (one process per GPU)")
+    kwargs = {}
+    if backend == "nccl":
+        from vitssl_hip.engine import configure_collectives
+        configure_collectives()
+        if device is not None:
+            kwargs["device_id"] = torch.device(device)
+    dist.init_process_group(backend, rank=int(os.environ["RANK"]), world_size=world, **kwargs)
+    logger.info("data parallel: rank %d of %d over %s", dist.get_rank(), dist.get_world_size(), backend)
+    return dist.get_world_size()
+
+
 def setup_device():
-    """One process per GPU: binds this process to cuda:LOCAL_RANK (torch.distributed.run exports it; 0 when run alone)
-    and returns that device.  The reference returns bare "cuda" or "cpu" (utils/train_utils.py:12-16); the engine has no
-    CPU path, so unlike the reference this refuses to hand out 'cpu'."""
+    """One process per GPU: binds this process to cuda:LOCAL_RANK (torch.distributed.run exports it; 0 when run alone),
+    joins the data-parallel job when there is one (`init_data_parallel`: nothing else on the reference's entry path,
+    train.py:107-128, would) and returns the device.  The reference returns bare "cuda" or "cpu"
+    (utils/train_utils.py:12-16); the engine has no CPU path, so unlike the reference this refuses to hand out 'cpu'.
+    VITSSL_SHARE_GPU=1 (rehearsal of N ranks on one card, with VITSSL_DIST_BACKEND=gloo) binds every rank to cuda:0."""
     if not torch.cuda.is_available():
         raise RuntimeError("no GPU visible: this engine runs the vit_core hot path on MI355X only (no CPU fallback)")
     index = int(os.environ.get("LOCAL_RANK", "0") or 0)
+    if os.environ.get("VITSSL_SHARE_GPU", "0") not in ("", "0"):
+        index = 0
     if not 0 <= index < torch.cuda.device_count():
         raise RuntimeError(f"LOCAL_RANK={index} but {torch.cuda.device_count()} GPU(s) are visible")
-    torch.cuda.set_device(index)
+    torch.cuda.set_device(index)                            # bind the GPU before RCCL sees the process
     device = torch.device(f"cuda:{index}")
+    init_data_parallel(device)
     logger.info("Using device: %s", device)
     return device
 
