@@ -10,7 +10,10 @@ A step = zero_grad -> mask draw -> forward -> L1 -> backward -> (RCCL gradient
 all-reduce, overlapped) -> AdamW, i.e. SimMIMViT.train_step.  Rank 0 prints ONE JSON
 line.  `value` is whole-job images/s; `roofline` is the dominant kernel family (the
 bf16 MFMA GEMMs) timed live with HIP events on the launch stream; `cpu_baseline` is the
-CPU oracle timed on this host's cores on a bounded sample (rank 0, N=1 only)."""
+CPU oracle timed on this host's cores on a bounded sample (rank 0, N=1 only).  On one GPU the
+default run then times the other BASELINE.json configurations (ViT-S/16 batch 256, ViT-L/16
+batch 128 in bf16 and with the fp8 weight path, ViT-B/16 DINO batch 64; 5 + 10 steps each) and
+appends them as `other_configs` -- after the headline's timed region, never inside it."""
 import argparse
 import json
 import os
@@ -57,21 +60,47 @@ def train_flops_per_image(D, L, H, F, N, Pd, nm):
     return 3 * (blocks + head) + 2 * proj
 
 
-def pmc_traffic_per_launch(family="gemm_nt"):
+def kernel_sources_sha16():
+    """Fingerprint of the kernel sources this build was made from (csrc/*.hip, *.cpp, *.h and the C header): the .git
+    directory does not travel to the GPU box, the sources do.  tools/profile_round.sh stamps it into the PMC summary."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "vit-ssl_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "vit-ssl_amd", "csrc", "*.cpp"))
+                   + glob.glob(os.path.join(ROOT, "vit-ssl_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic_per_launch(family="gemm_nt", profiles_dir=None):
     """HBM bytes per launch of the dominant kernel family from the committed rocprofv3 PMC
     passes (profiles/*_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate
     --pmc runs of this very command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
-    for gfx950's wide coalesced reads; unit KB).  None when no summary is committed."""
+    for gfx950's wide coalesced reads; unit KB).  Only a summary stamped with the fingerprint of
+    the kernel sources in this tree is used: a summary of other kernels must not label these.
+    Returns (bytes or None, source-or-reason)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-    if not files:
-        return None, None
-    d = json.load(open(files[-1]))
-    try:
-        f, w = d["FETCH_SIZE"][family], d["WRITE_SIZE"][family]
-        return (2.0 * f["sum_kb"] / f["dispatches"] + w["sum_kb"] / w["dispatches"]) * 1024.0, os.path.basename(files[-1])
-    except KeyError:
-        return None, None
+    sha = kernel_sources_sha16()
+    files = sorted(glob.glob(os.path.join(profiles_dir or os.path.join(ROOT, "profiles"), "*_pmc_traffic.json")))
+    stale = None
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if d.get("kernel_sources_sha16") != sha:
+            stale = stale or os.path.basename(f)
+            continue
+        try:
+            ft, w = d["FETCH_SIZE"][family], d["WRITE_SIZE"][family]
+            return (2.0 * ft["sum_kb"] / ft["dispatches"] + w["sum_kb"] / w["dispatches"]) * 1024.0, os.path.basename(f)
+        except KeyError:
+            continue
+    if stale:
+        return None, f"no PMC summary for kernel sources {sha} (newest committed: {stale}, other sources): run tools/profile_round.sh"
+    return None, None
 
 
 def _cpu_model():
@@ -122,6 +151,138 @@ def cpu_baseline(cfg, img, P, ratio, seconds_budget=25.0):
             "sample": f"same model/inputs shape, batch {Bc}, {len(times)} measured step(s) after 1 warm-up, fp32 eager, dropout 0.1, AdamW"}
 
 
+def families_from(recs):
+    """(fam, hbm, kernels) of one instrumented step: per kernel family algorithmic flops / live-event ms / launches; the
+    HBM-bound kernels by algorithmic bytes; per-label detail of the MFMA families."""
+    fam, hbm, kernels = {}, {}, {}
+    for label, flops, e0, e1, nbytes in recs:
+        ms = e0.elapsed_time(e1)
+        k = label.split("[")[0].split(" ")[0]
+        if nbytes:                                      # HBM-bound kernels: algorithmic bytes / time vs the 8 TB/s spec
+            h = hbm.setdefault(k, [0.0, 0.0, 0])
+            h[0] += nbytes
+            h[1] += ms
+            h[2] += 1
+            continue
+        for d, key in ((fam, k), (kernels, label)):
+            a = d.setdefault(key, [0.0, 0.0, 0])
+            a[0] += flops
+            a[1] += ms
+            a[2] += 1
+    return fam, hbm, kernels
+
+
+def peak_of(k):
+    return PEAK_FP8_TFLOPS if k in ("gemm_fp8_nt", "gemm_fp8_tn") else PEAK_BF16_TFLOPS
+
+
+KERNEL_NAMES = {"gemm_nt": "gemm_nt_pp_kernel", "gemm_tn": "gemm_tn_pp_kernel", "gemm_fp8_nt": "gemm_nt_pp_kernel<.., fp8>",
+                "gemm_fp8_tn": "gemm_tn_fp8_kernel"}
+
+
+def instrumented(step_fn):
+    """One extra step with every GEMM / attention / LayerNorm / AdamW launch bracketed by HIP events on the launch stream."""
+    from vitssl_hip import ops
+    ops.PROFILE = []
+    step_fn()
+    torch.cuda.synchronize()
+    recs, ops.PROFILE = ops.PROFILE, None
+    return families_from(recs)
+
+
+def short_roofline(fam):
+    """Dominant MFMA family of a side configuration: achieved TFLOP/s against the dense peak of its operand type."""
+    if not fam:
+        return None
+    name, (fl, ms, cnt) = max(fam.items(), key=lambda kv: kv[1][1])
+    ach = fl / (ms * 1e-3) / 1e12
+    return {"kernel": KERNEL_NAMES.get(name, name + "_kernel"), "bound": "mfma", "achieved": round(ach, 1), "peak": peak_of(name),
+            "unit": "TFLOP/s", "frac": round(ach / peak_of(name), 4), "launches_per_step": cnt, "ms_per_step": round(ms, 3)}
+
+
+def side_simmim(model_name, batch, dtype, dev, steps, warmup, img=224, patch=16, ratio=0.6, dropout=0.1):
+    """One of the other BASELINE.json SimMIM configurations, same step as the headline (train_step, dropout 0.1, AdamW)."""
+    from vit_core.ssl.simmim import SimMIMViT
+    from vitssl_hip import engine
+    from vitssl_hip.optim import FusedAdamW
+    cfg = MODELS[model_name]
+    engine.set_linear_operands(dtype)
+    torch.manual_seed(42)
+    model = SimMIMViT(num_blocks=cfg["L"], input_shape=(3, img, img), embed_dim=cfg["D"], patch_size=patch, num_heads=cfg["H"],
+                      mlp_dim=cfg["F"], dropout=dropout, mask_ratio=ratio).to(dev).train()
+    opt = FusedAdamW(model.flat_store(), lr=1e-4, weight_decay=1e-3)
+    x = torch.rand(batch, 3, img, img, generator=torch.Generator().manual_seed(42)).to(dev)
+    for _ in range(warmup):
+        loss = model.train_step(x, opt, None)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = model.train_step(x, opt, None)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    final = float(loss)
+    recomputed = float((model.last_pred - model.last_targets).abs().mean())
+    if not (final == final and abs(recomputed - final) <= 1e-4 * max(1.0, abs(final))):
+        raise SystemExit(f"bench sanity ({model_name} {dtype}): fused loss {final} vs recomputed {recomputed}")
+    fam, _, _ = instrumented(lambda: model.train_step(x, opt, None))
+    N = (img // patch) ** 2
+    fl = train_flops_per_image(cfg["D"], cfg["L"], cfg["H"], cfg["F"], N, 3 * patch * patch, int(N * ratio)) * batch
+    name = model_name.replace("_", "-").upper().replace("VIT-", "ViT-")
+    return {"workload": f"{name}/{patch} SimMIM {img}x{img} mask {ratio} dropout {dropout} AdamW, batch {batch}/GPU",
+            "dtype": "bf16" if dtype == "bf16" else "fp8 e4m3 Linear operands", "steps": steps, "warmup": warmup,
+            "ms_per_step": round(dt * 1e3, 3), "images_per_sec": round(batch / dt, 1), "unit": "images/s",
+            "mfma_util": round(fl / dt / 1e12 / PEAK_BF16_TFLOPS, 4), "final_loss": round(final, 5), "roofline": short_roofline(fam)}
+
+
+def side_dino(batch, dev, steps, warmup, dropout=0.1):
+    """BASELINE configs[3]: ViT-B/16 DINO, 2 x 224^2 global + 8 x 96^2 local crops, K = 65 536, EMA 0.996, tau_s 0.1, tau_t 0.04,
+    bf16 GEMMs, AdamW; views resident in HBM.  437.8 GF per image set."""
+    from vit_core.ssl.dino import DINOViT
+    from vit_core.ssl.dino.loss import DINOLoss
+    from vitssl_hip import engine
+    from vitssl_hip.optim import FusedAdamW
+    engine.set_linear_operands("bf16")
+    torch.manual_seed(42)
+    m = DINOViT(12, (3, 224, 224), 768, 16, 12, 3072, dropout, 65536, 0.9).to(dev).train()
+    opt = FusedAdamW(m.trainable_store(), lr=1e-4, weight_decay=1e-3)
+    crit = DINOLoss(0.04, 0.1)
+    views = [torch.rand(batch, 3, 224, 224, device=dev) for _ in range(2)] + [torch.rand(batch, 3, 96, 96, device=dev) for _ in range(8)]
+    step = lambda: m.train_step(views, 2, crit, opt, None, 0.996)  # noqa: E731
+    for _ in range(warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    final = float(loss)
+    if final != final:
+        raise SystemExit("bench sanity (DINO): loss is NaN")
+    fam, _, _ = instrumented(step)
+    return {"workload": f"ViT-B/16 DINO student+teacher, 2x224 + 8x96 crops, K=65536, EMA 0.996, dropout {dropout} AdamW, batch {batch} image sets/GPU",
+            "dtype": "bf16", "steps": steps, "warmup": warmup, "ms_per_step": round(dt * 1e3, 3),
+            "image_sets_per_sec": round(batch / dt, 1), "images_per_sec": round(10 * batch / dt, 1), "unit": "views/s (10 per image set)",
+            "mfma_util": round(437.8e9 * batch / dt / 1e12 / PEAK_BF16_TFLOPS, 4), "final_loss": round(final, 5),
+            "roofline": short_roofline(fam)}
+
+
+def other_configs(dev, steps=10, warmup=5):
+    """The BASELINE.json configurations other than the headline one, on this GPU, after the headline's timed region:
+    configs[1] ViT-S, configs[4] ViT-L in bf16 and with the fp8 weight path, configs[3] DINO (per-GPU batch 64)."""
+    import gc
+    rows = []
+    jobs = [lambda: side_simmim("vit_s", 256, "bf16", dev, steps, warmup),
+            lambda: side_simmim("vit_l", 128, "bf16", dev, steps, warmup),
+            lambda: side_simmim("vit_l", 128, "fp8", dev, steps, warmup),
+            lambda: side_dino(64, dev, steps, warmup)]
+    for job in jobs:
+        rows.append(job())
+        gc.collect()
+        torch.cuda.empty_cache()
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,6 +299,9 @@ def main():
                          "everything else stay bf16).  The headline metric is bf16.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the side runs of the other BASELINE configurations (ViT-S, ViT-L bf16 / fp8, DINO) that follow the "
+                         "headline's timed region on one GPU")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: all ranks use cuda:0")
     args = ap.parse_args()
@@ -264,37 +428,13 @@ def main():
     roofline = None
     kernels = {}
     if not args.no_kernel_timing:
-        ops.PROFILE = []
-        model.train_step(x, opt, reducer)
-        torch.cuda.synchronize()
-        recs, ops.PROFILE = ops.PROFILE, None
-        fam = {}
-        hbm = {}
-        for label, flops, e0, e1, nbytes in recs:
-            ms = e0.elapsed_time(e1)
-            k = label.split("[")[0].split(" ")[0]
-            if nbytes:                                      # HBM-bound kernels: algorithmic bytes / time vs the 8 TB/s spec
-                h = hbm.setdefault(k, [0.0, 0.0, 0])
-                h[0] += nbytes
-                h[1] += ms
-                h[2] += 1
-                continue
-            a = fam.setdefault(k, [0.0, 0.0, 0])
-            a[0] += flops
-            a[1] += ms
-            a[2] += 1
-            b = kernels.setdefault(label, [0.0, 0.0, 0])
-            b[0] += flops
-            b[1] += ms
-            b[2] += 1
+        fam, hbm, kernels = instrumented(lambda: model.train_step(x, opt, reducer))
         dom = max(fam.items(), key=lambda kv: kv[1][1])
         name, (fl, ms, cnt) = dom
         ach = fl / (ms * 1e-3) / 1e12
         traffic, traffic_src = (pmc_traffic_per_launch(name) if args.model == "vit_b" and args.batch == 256 and args.dtype == "bf16"
                                 else (None, None))
-        peak_of = lambda k: PEAK_FP8_TFLOPS if k in ("gemm_fp8_nt", "gemm_fp8_tn") else PEAK_BF16_TFLOPS  # noqa: E731
-        roofline = {"kernel": {"gemm_nt": "gemm_nt_pp_kernel", "gemm_tn": "gemm_tn_pp_kernel",
-                               "gemm_fp8_nt": "gemm_nt_pp_kernel<.., fp8>", "gemm_fp8_tn": "gemm_tn_fp8_kernel"}.get(name, name + "_kernel"),
+        roofline = {"kernel": KERNEL_NAMES.get(name, name + "_kernel"),
                     "bound": "mfma", "achieved": round(ach, 1), "peak": peak_of(name),
                     "unit": "TFLOP/s", "frac": round(ach / peak_of(name), 4),
                     "traffic": None if traffic is None else round(traffic), "traffic_unit": "bytes/launch (HBM, PMC)",
@@ -306,6 +446,17 @@ def main():
                     "hbm": {k: {"achieved_tbs": round(v[0] / (v[1] * 1e-3) / 1e12, 2), "peak_tbs": PEAK_HBM_TBS,
                                 "frac": round(v[0] / (v[1] * 1e-3) / 1e12 / PEAK_HBM_TBS, 3), "ms_per_step": round(v[1], 3),
                                 "launches": v[2], "alg_bytes_per_launch": round(v[0] / v[2])} for k, v in hbm.items()}}
+
+    # ---- the other BASELINE configurations, after (never inside) the headline's timed region; one GPU only
+    others = None
+    headline = (args.model, args.batch, args.dtype, args.img, args.patch) == ("vit_b", 256, "bf16", 224, 16)
+    if world == 1 and headline and not args.no_other_configs:
+        import gc
+        last = (model.last_pred, model.last_targets)
+        del model, store, opt, x, last
+        gc.collect()
+        torch.cuda.empty_cache()
+        others = other_configs(dev)
 
     if rank == 0:
         out = {
@@ -326,6 +477,8 @@ def main():
         }
         if dp is not None:
             out["data_parallel"] = dp
+        if others is not None:
+            out["other_configs"] = others
         if os.environ.get("BENCH_KERNELS"):
             out["kernels"] = {k: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1), "ms": round(v[1], 3), "n": v[2]} for k, v in kernels.items()}
         print(json.dumps(out))

@@ -2,7 +2,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for sg in 0 1; do
   export VITSSL_NT_STAGGER=$sg
   rm -rf gpurun_out/fetch_sg$sg
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/fetch_sg$sg -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > /dev/null 2>&1
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/fetch_sg$sg -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-other-configs > /dev/null 2>&1
 done
 python3 - <<'PY'
 import csv, glob, collections, re

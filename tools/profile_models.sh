@@ -15,14 +15,14 @@ run() {  # name, then the program and its arguments
   find $out/$name -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${tag}_${name}_kernel_stats.csv
   echo "profiled $name" >&2
 }
-python3 bench.py --model vit_s --no-cpu-baseline >> $log 2>/dev/null
-python3 bench.py --model vit_l --batch 128 --no-cpu-baseline >> $log 2>/dev/null
-python3 bench.py --model vit_l --batch 128 --dtype fp8 --no-cpu-baseline >> $log 2>/dev/null
+python3 bench.py --model vit_s --no-cpu-baseline --no-other-configs >> $log 2>/dev/null
+python3 bench.py --model vit_l --batch 128 --no-cpu-baseline --no-other-configs >> $log 2>/dev/null
+python3 bench.py --model vit_l --batch 128 --dtype fp8 --no-cpu-baseline --no-other-configs >> $log 2>/dev/null
 python3 tools/bench_dino.py >> $log 2>/dev/null
 python3 tools/bench_dino.py --raw >> $log 2>/dev/null || true
-run vit_s bench.py --model vit_s --steps 8 --warmup 3 --no-cpu-baseline --no-kernel-timing
-run vit_l bench.py --model vit_l --batch 128 --steps 8 --warmup 3 --no-cpu-baseline --no-kernel-timing
-run vit_l_fp8 bench.py --model vit_l --batch 128 --dtype fp8 --steps 8 --warmup 3 --no-cpu-baseline --no-kernel-timing
+run vit_s bench.py --model vit_s --steps 8 --warmup 3 --no-cpu-baseline --no-other-configs --no-kernel-timing
+run vit_l bench.py --model vit_l --batch 128 --steps 8 --warmup 3 --no-cpu-baseline --no-other-configs --no-kernel-timing
+run vit_l_fp8 bench.py --model vit_l --batch 128 --dtype fp8 --steps 8 --warmup 3 --no-cpu-baseline --no-other-configs --no-kernel-timing
 run dino tools/bench_dino.py --steps 6 --warmup 2
 # the same lines as one JSON document (copy to profiles/<tag>_configs.json)
 python3 - "$log" "gpurun_out/${tag}_configs.json" <<'PY'

@@ -11,10 +11,10 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/prof_$tag
 rm -rf $out
 python3 bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-kernel-timing > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-other-configs > /dev/null 2>&1
 find $out/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${tag}_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d $out/$c -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > /dev/null 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $out/$c -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-other-configs > /dev/null 2>&1
 done
 python3 - "$out" "gpurun_out/${tag}_pmc_traffic.json" <<'PY'
 import csv, glob, json, sys, collections
@@ -32,6 +32,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             a["sum_kb"] += float(r["Counter_Value"])
             a["dispatches"] += 1
     res[c] = agg
+sys.path.insert(0, ".")
+import bench
+res["kernel_sources_sha16"] = bench.kernel_sources_sha16()     # bench.py only quotes a summary of THESE kernel sources
 res["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 2 --warmup 1`; "
                "unit KB as reported; FETCH_SIZE must be doubled on gfx950 for wide coalesced reads (MI355X_MICROARCH.md)")
 json.dump(res, open(dst, "w"), indent=1)
