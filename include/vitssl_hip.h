@@ -38,7 +38,7 @@ int vitssl_version(void);
 
 /* ---- CUs left to other kernels (data parallelism; no reference counterpart: the reference is single-device,
  *      utils/train_utils.py:12-16) -------------------------------------------------------------------------
- * The forward / input-gradient / weight-gradient GEMMs and the LayerNorm backward run ONE persistent workgroup per
+ * The forward / input-gradient / weight-gradient GEMMs, the persistent attention forward and the LayerNorm backward run ONE persistent workgroup per
  * CU that owns the CU's whole register file and 129 of its 160 KiB of LDS, so the collective library's all-reduce
  * kernels cannot share a CU with them.  vitssl_set_reserved_cus(n) makes every persistent grid launched AFTER the
  * call leave n CUs unoccupied (clamped to [0, CUs - 8]; process-wide; read on every launch, so the order of
@@ -46,6 +46,7 @@ int vitssl_version(void);
 int vitssl_set_reserved_cus(int n);
 int vitssl_get_reserved_cus(void);          /* returns the count in force (not an error code) */
 int vitssl_debug_last_nt_grid(void);        /* workgroups of the last persistent NT GEMM launch (tests) */
+int vitssl_debug_last_attn_fwd_grid(void);  /* workgroups of the last attention-forward launch (tests) */
 
 /* ---- dropout stream -------------------------------------------------------
  * Counter-based: keep(e) = [bits16(seed, site, e) >= round(p * 65536)] for element index e = row * cols + col of the
@@ -317,12 +318,15 @@ int vitssl_weightnorm_bwd(const float* dw, const float* g, const float* v, const
                           int D, void* stream);
 /* DINOLoss: teacher f32 [G,B,K], student f32 [V,B,K], center f32 [K];
  * loss_sum += -(1/(G B K)) sum_{b,k} (sum_g softmax((t-c)/tt))(sum_v log_softmax(s/ts));
- * dstudent bf16 [V,B,K] = gscale * dloss/dstudent (or NULL); t_ws f32 scratch of B*K + VITSSL_DINO_TWS_EXTRA(G,B) floats
- * ([B,K] teacher probabilities, then the per-slice softmax statistics of the teacher rows). */
+ * dstudent bf16 [V,B,K] = gscale * dloss/dstudent (or NULL); t_ws = f32 scratch of t_ws_floats >=
+ * vitssl_dino_loss_workspace_floats(G, B, K) floats ([B,K] teacher probabilities, then the per-slice softmax statistics of
+ * the teacher rows: B*K + VITSSL_DINO_TWS_EXTRA(G,B)); a smaller buffer is refused (ABI version 2: version 1 took the bare
+ * pointer and wrote the statistics behind [B,K] unchecked). */
 #define VITSSL_DINO_TWS_EXTRA(G, B) (8 * (G) * (B))
-int vitssl_dino_loss(const float* teacher, const float* student, const float* center, float* t_ws, float* loss_sum,
-                     void* dstudent_bf16, int G, int V, int B, int K, float teacher_temp, float student_temp, float gscale,
-                     void* stream);
+int64_t vitssl_dino_loss_workspace_floats(int G, int B, int K);
+int vitssl_dino_loss(const float* teacher, const float* student, const float* center, float* t_ws, int64_t t_ws_floats,
+                     float* loss_sum, void* dstudent_bf16, int G, int V, int B, int K, float teacher_temp, float student_temp,
+                     float gscale, void* stream);
 /* out[cols] = column sums of x f32 [rows, cols] (overwrites) */
 int vitssl_colsum_f32(const float* x, float* out, int64_t rows, int cols, void* stream);
 /* center = m center + (1-m) colsum * inv_rows   (all-reduce colsum first under data parallelism) */

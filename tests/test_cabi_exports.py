@@ -27,10 +27,10 @@ def test_exports_every_header_symbol(built):
     from vitssl_hip import _lib
     declared = set(syms) - {"vitssl_last_error", "vitssl_version", "vitssl_gemm_tn_workspace_floats",
                             "vitssl_gemm_fp8_tn_workspace_floats", "vitssl_embed_bwd_workspace_floats",
-                            "vitssl_gemm_tn_batch_workspace_floats", "vitssl_gemm_fp8_tn_batch_workspace_floats",
-                            "vitssl_get_reserved_cus", "vitssl_debug_last_nt_grid"}
+                            "vitssl_gemm_tn_batch_workspace_floats", "vitssl_gemm_fp8_tn_batch_workspace_floats", "vitssl_dino_loss_workspace_floats",
+                            "vitssl_get_reserved_cus", "vitssl_debug_last_nt_grid", "vitssl_debug_last_attn_fwd_grid"}
     assert declared == set(_lib.PROTOTYPES), "Python prototypes out of sync with the header"
-    assert built.lib().vitssl_version() >= 1
+    assert built.lib().vitssl_version() >= 2
 
 
 def test_no_cpu_fallback(built):

@@ -27,21 +27,26 @@ def _mul(a, c):
 
 
 def drop_key(seed: int, site: int):
-    """make_drop_key: (k0, k1) from (seed, site) -- a splitmix-style 64-bit mix."""
+    """make_drop_key: (k0, k1, k2) from (seed, site) -- a splitmix-style 64-bit mix, and a second round of it for k2."""
     m = (1 << 64) - 1
     s = (seed * 0x9E3779B97F4A7C15 + (site + 1) * 0xD1B54A32D192ED03) & m
     s ^= s >> 29
     s = (s * 0xBF58476D1CE4E5B9) & m
     s ^= s >> 32
-    return U32(s & 0xFFFFFFFF), U32(s >> 32)
+    t = (s * 0x94D049BB133111EB) & m
+    t ^= t >> 31
+    return U32(s & 0xFFFFFFFF), U32(s >> 32), U32((t >> 16) & 0xFFFFFFFF)
 
 
-def drop_words(g, k0, k1):
-    """drop_words: group counter g (uint32 array) -> the two state words (a, b)."""
+def drop_words(g, k0, k1, k2):
+    """drop_words: group counter g (uint32 array) -> the two state words (a, b).  Round 4: the key also enters word a -- its first
+    multiplier is the odd number M1 ^ (k1 << 1) and k2 is xored in between the two multiplies.  With the key in word b only, the
+    a-words of any two keys were shifted windows of ONE 2^32-long sequence (test_streams_of_different_keys_are_not_shifted_copies).
+    Same instruction count on the GPU: the multiplier is a scalar operand either way and the xor fuses into v_xor3_b32."""
     a = (_mul(g.astype(np.uint32), C0) + k0).astype(np.uint32)
     a = a ^ (a >> U32(15))
-    a = _mul(a, 0x2C1B3C6D)
-    a = a ^ (a >> U32(12))
+    a = _mul(a, ((0x2C1B3C6D ^ (int(k1) << 1)) & 0xFFFFFFFF) | 1)
+    a = a ^ (a >> U32(12)) ^ k2
     a = _mul(a, 0x297A2D39)
     a = a ^ (a >> U32(15))
     b = _mul(a ^ k1, 0xC2B2AE35)
@@ -54,9 +59,9 @@ def keep_mask(rows: int, cols: int, p: float, seed: int, site: int) -> np.ndarra
     thr = min(int(p * 65536.0 + 0.5), 65535) if p > 0 else 0
     if thr == 0:
         return np.ones((rows, cols), np.uint8)
-    k0, k1 = drop_key(seed, site)
+    k0, k1, k2 = drop_key(seed, site)
     g = np.arange(rows * cols // 4, dtype=np.uint64).astype(np.uint32)
-    a, b = drop_words(g, k0, k1)
+    a, b = drop_words(g, k0, k1, k2)
     u = np.stack([a & U32(0xFFFF), a >> U32(16), b & U32(0xFFFF), b >> U32(16)], -1).astype(np.int64)
     s16 = np.where(u >= 32768, u - 65536, u)                   # the 16 bits read as a signed number
     return (s16 >= thr - 32768).astype(np.uint8).reshape(rows, cols)
@@ -97,9 +102,9 @@ def test_stream_statistics(cols, seed, p):
 
 
 def test_16bit_values_are_uniform():
-    k0, k1 = drop_key(2024, 1)
+    k0, k1, k2 = drop_key(2024, 1)
     g = np.arange(1 << 22, dtype=np.uint64).astype(np.uint32)
-    a, b = drop_words(g, k0, k1)
+    a, b = drop_words(g, k0, k1, k2)
     for w in (a, b):
         for half in (w & U32(0xFFFF), w >> U32(16)):
             cnt = np.bincount(half.astype(np.int64), minlength=65536)
@@ -116,6 +121,36 @@ def test_streams_of_different_keys_are_uncorrelated():
         other = keep_mask(rows, cols, p, seed, site).astype(np.float64) - pe
         z = (base * other).mean() / (pe * (1 - pe)) * math.sqrt(base.size)
         assert abs(z) < 4.5, (seed, site, z)
+
+
+def test_streams_of_different_keys_are_not_shifted_copies():
+    """Round-3 advisor finding: word a (elements 0 and 1 of every group) was a fixed bijection of g * C0 + k0, so the a-streams of
+    ANY two (seed, site) keys were the same 2^32-long sequence read at an offset of (k0' - k0) * C0^-1 groups -- with 36 sites per
+    step and a new seed every step, exact shifted repeats of half the mask bits inside one tensor's range were frequent.  With k1
+    mixed in between the two multiplies, the streams at exactly that offset must be unrelated."""
+    c0_inv = pow(C0, -1, 1 << 32)
+    n = 1 << 20
+    p = 0.1
+    thr_s = int(p * 65536.0 + 0.5) - 32768
+    pe = 1.0 - round(p * 65536) / 65536
+    rng = np.random.default_rng(0)
+    pairs = [((1234, 3), (1234, 4)), ((1234, 3), (1235, 3)), ((7, 0), (2 ** 40 + 1, 35))]
+    pairs += [((int(rng.integers(1 << 40)), int(rng.integers(36))), (int(rng.integers(1 << 40)), int(rng.integers(36)))) for _ in range(9)]
+    for (sa, ia), (sb, ib) in pairs:
+        ka, kb = drop_key(sa, ia), drop_key(sb, ib)
+        shift = ((int(kb[0]) - int(ka[0])) * c0_inv) % (1 << 32)        # (g + shift) * C0 + k0a == g * C0 + k0b  (mod 2^32)
+        g = np.arange(n, dtype=np.uint64)
+        aa, ba = drop_words(((g + shift) & 0xFFFFFFFF).astype(np.uint32), *ka)
+        ab, bb = drop_words(g.astype(np.uint32), *kb)
+        assert (aa == ab).mean() < 1e-4 and (ba == bb).mean() < 1e-4
+        for wa, wb in ((aa, ab), (ba, bb)):
+            for sh in (0, 16):
+                ua = ((wa >> U32(sh)) & U32(0xFFFF)).astype(np.int64)
+                ub = ((wb >> U32(sh)) & U32(0xFFFF)).astype(np.int64)
+                ka_ = (np.where(ua >= 32768, ua - 65536, ua) >= thr_s) - pe
+                kb_ = (np.where(ub >= 32768, ub - 65536, ub) >= thr_s) - pe
+                z = (ka_ * kb_).mean() / (pe * (1 - pe)) * math.sqrt(n)
+                assert abs(z) < 4.5, (sa, ia, sb, ib, sh, z)
 
 
 # --------------------------------------------------------------------------------------------- the kernels use exactly this stream

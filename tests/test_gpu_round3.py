@@ -41,7 +41,17 @@ def test_reserved_cus_take_effect_after_a_forward(monkeypatch):
         ops.gemm_tn(dY, X, C)
         ref = dY.float().t() @ X.float()
         assert float((C - ref).norm() / ref.norm()) < 1e-5
+        # the persistent attention forward owns a CU per workgroup for the whole launch: its grid leaves the reserve alone too
+        Bq, Hq, Nq = 40, 8, 196                          # 320 (batch, head) items > CUs
+        qkv = (torch.randn(Bq * Nq, 3 * Hq * 64, device=DEV) * 0.5).to(torch.bfloat16)
+        o1, o0 = (torch.empty(Bq * Nq, Hq * 64, dtype=torch.bfloat16, device=DEV) for _ in range(2))
+        lse1, lse0 = (torch.empty(Bq, Hq, Nq, device=DEV) for _ in range(2))
+        ops.attn_fwd(qkv, o1, lse1, Bq, Nq, Hq, 64)
+        assert lib.vitssl_debug_last_attn_fwd_grid() == cus - 8
         L.call("vitssl_set_reserved_cus", 0)
+        ops.attn_fwd(qkv, o0, lse0, Bq, Nq, Hq, 64)
+        assert lib.vitssl_debug_last_attn_fwd_grid() == cus
+        assert torch.equal(o0, o1) and torch.equal(lse0, lse1)
         ops.gemm_nt(A, B, out1, L.EPI_BF16)
         assert lib.vitssl_debug_last_nt_grid() == cus
         with pytest.raises(L.VitsslError, match="negative"):

@@ -92,7 +92,8 @@ def main():
     if os.environ.get("MODE") == "tn":
         return tn_mode(names, libs, M, rounds, iters, st)
     for (N, K) in shapes:
-        A, B = rb(M, K), rb(N, K)
+        pad = int(os.environ.get("LDPAD", 0))             # probe builds with -DNT_PROBE_LDPAD=pad read rows K + pad elements apart
+        A, B = rb(M, K + pad), rb(N, K + pad)
         if os.environ.get("UNIT_OUT", "1") != "0":          # outputs ~ N(0, 1) like a model's pre-activations (0.5 * 0.5 * sqrt(K) otherwise)
             B = (B.float() * (4.0 / K ** 0.5)).to(torch.bfloat16)
         bias = torch.randn(N, device=DEV) * 0.1

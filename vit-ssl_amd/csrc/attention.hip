@@ -624,238 +624,10 @@ __global__ __launch_bounds__(1024 / QT, QT == 1 ? 4 : 2) void attn_fwd_pers_kern
 #undef PSTAMP
 }
 
-// ------------------------------------------------------------------ backward: dK, dV
-// grid = B*H, 512 threads: wave w owns keys [32w, 32w+32).  Q and dO tiles in LDS.
-template <int NS>
-__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
-                                                           const float* __restrict__ lse, const float* __restrict__ delta,
-                                                           bf16_t* __restrict__ dqkv, int N, int H) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int Np = 32 * NS;
-  char* Qt = smem;
-  char* Dt = smem + Np * ROWB;
-  float* lse_s = (float*)(smem + 2 * Np * ROWB);
-  float* del_s = lse_s + Np;
-  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
-  const long long stride = 3LL * H * DH;
-  const bf16_t* qg = qkv + (long long)b * N * stride + h * DH;
-  const bf16_t* kg = qg + (long long)H * DH;
-  const bf16_t* vg = kg + (long long)H * DH;
-  const bf16_t* dog = dout + (long long)b * N * (H * DH) + h * DH;
-  {
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    dma_tile<8>(Qt, qg, stride, N, Np, wv, threadIdx.x & 63);
-    dma_tile<8>(Dt, dog, (long long)H * DH, N, Np, wv, threadIdx.x & 63);
-  }
-  for (int i = threadIdx.x; i < Np; i += 512) {
-    // stored pre-multiplied (log2(e), 1/sqrt(dh)) so that the loop needs one fused
-    // multiply-add per score; padded queries: +inf makes p = exp2(x - inf) = 0
-    lse_s[i] = i < N ? lse[((long long)b * H + h) * N + i] * LOG2E : INFINITY;
-    del_s[i] = i < N ? delta[((long long)b * H + h) * N + i] * SCALE : 0.f;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (wave * 32 >= N) return;  // wave-uniform; no barrier below
-  const int g = lane >> 4, li = lane & 15;
-  const f32x4 c4 = {SCALE_LOG2E, SCALE_LOG2E, SCALE_LOG2E, SCALE_LOG2E}, sc4 = {SCALE, SCALE, SCALE, SCALE};
-
-  bf16x8 kf[2][2], vf[2][2];
-#pragma unroll
-  for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int key = wave * 32 + kt * 16 + li;
-      kf[kt][kk] = glb_frag(kg, stride, key, kk, N, lane);
-      vf[kt][kk] = glb_frag(vg, stride, key, kk, N, lane);
-    }
-  f32x4 dv[4][2], dk[4][2];
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      dv[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      dk[dt][kt] = dv[dt][kt];
-    }
-
-#pragma unroll 1
-  for (int qs = 0; qs < NS; ++qs) {
-    f32x4 p[2][2], ds[2][2];  // [query tile in step][key tile]
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int qrow = qs * 32 + t * 16 + li;
-      const bf16x8 qa0 = lds_frag(Qt, qrow, 0, lane), qa1 = lds_frag(Qt, qrow, 1, lane);
-      const bf16x8 da0 = lds_frag(Dt, qrow, 0, lane), da1 = lds_frag(Dt, qrow, 1, lane);
-      // this lane's four queries of the tile: -lse*log2(e) and -delta*scale
-      const f32x4 nl = -*(const f32x4*)(lse_s + qs * 32 + t * 16 + 4 * g);
-      const f32x4 nd = -*(const f32x4*)(del_s + qs * 32 + t * 16 + 4 * g);
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
-        a = MFMA16(qa0, kf[kt][0], a);
-        a = MFMA16(qa1, kf[kt][1], a);
-        c = MFMA16(da0, vf[kt][0], c);
-        c = MFMA16(da1, vf[kt][1], c);
-        // keys >= N need no mask here: their dK / dV rows are never stored
-        const f32x4 e = __builtin_elementwise_fma(a, c4, nl);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) p[t][kt][r] = __builtin_amdgcn_exp2f(e[r]);
-        ds[t][kt] = p[t][kt] * __builtin_elementwise_fma(c, sc4, nd);
-      }
-    }
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      const bf16x8 pf = pack_frag(p[0][kt], p[1][kt]);
-      const bf16x8 sf = pack_frag(ds[0][kt], ds[1][kt]);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        dv[dt][kt] = MFMA16(tr_frag(Dt, qs, dt, lane), pf, dv[dt][kt]);
-        dk[dt][kt] = MFMA16(tr_frag(Qt, qs, dt, lane), sf, dk[dt][kt]);
-      }
-    }
-  }
-#pragma unroll
-  for (int kt = 0; kt < 2; ++kt) {
-    const int key = wave * 32 + kt * 16 + li;
-    if (key < N) {
-      bf16_t* dkg = dqkv + ((long long)b * N + key) * stride + (long long)H * DH + h * DH;
-      bf16_t* dvg = dkg + (long long)H * DH;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        u32x2 wk = {pack_bf2(dk[dt][kt][0], dk[dt][kt][1]), pack_bf2(dk[dt][kt][2], dk[dt][kt][3])};
-        u32x2 wv = {pack_bf2(dv[dt][kt][0], dv[dt][kt][1]), pack_bf2(dv[dt][kt][2], dv[dt][kt][3])};
-        *(u32x2*)(dkg + dt * 16 + 4 * g) = wk;
-        *(u32x2*)(dvg + dt * 16 + 4 * g) = wv;
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------ backward: dQ
-// grid = B*H, 256 threads (2 workgroups per CU): waves own PAIRS of 16-query tiles;
-// K and V tiles in LDS, each fragment read feeds both tiles.
-template <int NS>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ outp,
-                                                             const bf16_t* __restrict__ dout, const float* __restrict__ lse,
-                                                             float* __restrict__ delta, bf16_t* __restrict__ dqkv, int N, int H) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int Np = 32 * NS;
-  constexpr int NKT = 2 * NS;
-  char* Kt = smem;
-  char* Vt = smem + Np * ROWB;
-  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
-  const long long stride = 3LL * H * DH;
-  const bf16_t* qg = qkv + (long long)b * N * stride + h * DH;
-  const bf16_t* kg = qg + (long long)H * DH;
-  const bf16_t* vg = kg + (long long)H * DH;
-  const bf16_t* dog = dout + (long long)b * N * (H * DH) + h * DH;
-  const bf16_t* og = outp + (long long)b * N * (H * DH) + h * DH;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int g = lane >> 4, li = lane & 15;
-  const int nqp = (N + 31) >> 5;
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  const f32x4 tail0 = key_mask_init(NKT - 2, g, N), tail1 = key_mask_init(NKT - 1, g, N);
-  const f32x4 c4 = {SCALE_LOG2E, SCALE_LOG2E, SCALE_LOG2E, SCALE_LOG2E}, sc4 = {SCALE, SCALE, SCALE, SCALE};
-  dma_tile<4>(Kt, kg, stride, N, Np, wave, lane);
-  dma_tile<4>(Vt, vg, stride, N, Np, wave, lane);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-  for (int qp = wave; qp < nqp; qp += 4) {
-    const int q[2] = {qp * 32 + li, qp * 32 + 16 + li};
-    bf16x8 qf[2][2], df[2][2];
-    float l[2], dl[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      qf[t][0] = glb_frag(qg, stride, q[t], 0, N, lane);
-      qf[t][1] = glb_frag(qg, stride, q[t], 1, N, lane);
-      df[t][0] = glb_frag(dog, (long long)H * DH, q[t], 0, N, lane);
-      df[t][1] = glb_frag(dog, (long long)H * DH, q[t], 1, N, lane);
-      l[t] = q[t] < N ? lse[((long long)b * H + h) * N + q[t]] : INFINITY;
-      // delta[q] = sum_d dO[q][d] O[q][d]: this lane holds 16 of the 64 d of its query
-      // (fragment positions 32kk + 8g + j); reduce over the 4 lane groups.
-      float part = 0.f;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const u32x4 ov = __builtin_bit_cast(u32x4, glb_frag(og, (long long)H * DH, q[t], kk, N, lane));
-        const u32x4 dv = __builtin_bit_cast(u32x4, df[t][kk]);
-#pragma unroll
-        for (int w = 0; w < 4; ++w) part += bf_lo(ov[w]) * bf_lo(dv[w]) + bf_hi(ov[w]) * bf_hi(dv[w]);
-      }
-      part += __shfl_xor(part, 16, 64);
-      part += __shfl_xor(part, 32, 64);
-      dl[t] = part;
-      if (q[t] < N && g == 0) delta[((long long)b * H + h) * N + q[t]] = part;
-    }
-    // per-query constants of the fused score pipeline; padded queries: lse = +inf -> p = 0
-    const float nl0 = -l[0] * LOG2E, nl1 = -l[1] * LOG2E, nd0 = -dl[0] * SCALE, nd1 = -dl[1] * SCALE;
-    const f32x4 nl0v = {nl0, nl0, nl0, nl0}, nl1v = {nl1, nl1, nl1, nl1};
-    const f32x4 nd0v = {nd0, nd0, nd0, nd0}, nd1v = {nd1, nd1, nd1, nd1};
-    f32x4 ds0[NKT], ds1[NKT];
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      const bf16x8 k0 = lds_frag(Kt, kt * 16 + li, 0, lane), k1 = lds_frag(Kt, kt * 16 + li, 1, lane);
-      const bf16x8 v0 = lds_frag(Vt, kt * 16 + li, 0, lane), v1 = lds_frag(Vt, kt * 16 + li, 1, lane);
-      // masked keys start at -inf: p = exp2(-inf) = 0 (V rows >= N are zero, so dP stays finite)
-      f32x4 a0 = kt == NKT - 2 ? tail0 : (kt == NKT - 1 ? tail1 : zero4), a1 = a0, c0 = zero4, c1 = zero4;
-      a0 = MFMA16(k0, qf[0][0], a0);
-      a1 = MFMA16(k0, qf[1][0], a1);
-      c0 = MFMA16(v0, df[0][0], c0);
-      c1 = MFMA16(v0, df[1][0], c1);
-      a0 = MFMA16(k1, qf[0][1], a0);
-      a1 = MFMA16(k1, qf[1][1], a1);
-      c0 = MFMA16(v1, df[0][1], c0);
-      c1 = MFMA16(v1, df[1][1], c1);
-      const f32x4 e0 = __builtin_elementwise_fma(a0, c4, nl0v), e1 = __builtin_elementwise_fma(a1, c4, nl1v);
-      f32x4 p0, p1;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        p0[r] = __builtin_amdgcn_exp2f(e0[r]);
-        p1[r] = __builtin_amdgcn_exp2f(e1[r]);
-      }
-      ds0[kt] = p0 * __builtin_elementwise_fma(c0, sc4, nd0v);
-      ds1[kt] = p1 * __builtin_elementwise_fma(c1, sc4, nd1v);
-      __builtin_amdgcn_sched_barrier(0);   // keep fragment live ranges per key tile (256-VGPR budget)
-    }
-    f32x4 dq0[4], dq1[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      dq0[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      dq1[dt] = dq0[dt];
-    }
-#pragma unroll
-    for (int st = 0; st < NS; ++st) {
-      const bf16x8 f0 = pack_frag(ds0[2 * st], ds0[2 * st + 1]);
-      const bf16x8 f1 = pack_frag(ds1[2 * st], ds1[2 * st + 1]);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const bf16x8 kf = tr_frag(Kt, st, dt, lane);
-        dq0[dt] = MFMA16(kf, f0, dq0[dt]);
-        dq1[dt] = MFMA16(kf, f1, dq1[dt]);
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      if (q[t] < N) {
-        bf16_t* dqg = dqkv + ((long long)b * N + q[t]) * stride + h * DH;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          const f32x4 o = t == 0 ? dq0[dt] : dq1[dt];
-          u32x2 w = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
-          *(u32x2*)(dqg + dt * 16 + 4 * g) = w;
-        }
-      }
-    }
-  }
-}
-
 // ------------------------------------------------------------------ backward, fused (one launch)
 // grid = B*H, 512 threads.  Wave w < NS owns keys [32w, 32w+32): it holds their K / V row
 // fragments in registers, sweeps the queries in steps of 32 and accumulates dK / dV exactly
-// like the split dK/dV kernel.  The dS tile of every step is also dropped (bf16) into a
+// like a key-stationary dK / dV kernel.  The dS tile of every step is also dropped (bf16) into a
 // double-buffered LDS exchange image [32 queries][Np keys]; after one barrier the eight
 // waves each take one (16-query tile, 16-column slice) of dQ for those 32 queries and
 // contract over ALL keys from that image -- S and dP are computed once instead of twice,
@@ -1471,51 +1243,37 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(const bf16_t* __rest
 }
 
 
-int attn_cu_count() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-    if (n <= 0) n = 256;
-  }
-  return n;
-}
+// CUs the launches of this file size themselves for: the device's count minus the reserve in force (vitssl_set_reserved_cus).  The
+// persistent forward holds 147-160 KiB of LDS and 8 waves x 256 VGPRs per workgroup, i.e. a whole CU for the whole launch, so its grid
+// must leave the reserved CUs to the collective library like the GEMM grids do (round-3 advisor finding: it used the raw count).
+int attn_cu_count() { return vitssl_persistent_cus(); }
+std::atomic<int> g_last_attn_fwd_grid{0};
 
-// stagger window in 10 ns ticks: VITSSL_ATTN_STAGGER="fwd,bwd" (default below; 0 disables)
+// stagger window in 10 ns ticks: VITSSL_ATTN_STAGGER_FWD / _BWD (developer knobs; 0 disables)
 int attn_stagger_ticks(int which) {
-  static int v[2] = {-1, -1};
-  if (v[0] < 0) {
-    v[0] = 0;        // forward: two workgroups per CU already overlap each other's loads (stagger measured -2 %)
-    v[1] = 1400;     // fused backward (one workgroup per CU): prologue 6.5 -> 4.9 us per workgroup, launch 269 -> 265 us
-    const char* e = getenv("VITSSL_ATTN_STAGGER");
-    if (e) sscanf(e, "%d,%d", &v[0], &v[1]);
-  }
-  return v[which];
+  static VsEnvInt fwd, bwd;
+  // forward: two workgroups per CU already overlap each other's loads (stagger measured -2 %)
+  // fused backward (one workgroup per CU): prologue 6.5 -> 4.9 us per workgroup, launch 269 -> 265 us
+  return which == 0 ? fwd.get("VITSSL_ATTN_STAGGER_FWD", 0) : bwd.get("VITSSL_ATTN_STAGGER_BWD", 1400);
 }
 
 template <typename K>
-int ensure_lds(K kernel, int bytes, bool* done, const char* who) {
-  if (*done || bytes <= 48 * 1024) return VITSSL_OK;
+int ensure_lds(K kernel, int bytes, VsOnce* done, const char* who) {
+  if (done->load(std::memory_order_relaxed) || bytes <= 48 * 1024) return VITSSL_OK;
   hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) {
     vitssl_set_error("%s: cannot raise dynamic LDS: %s", who, hipGetErrorString(e));
     return VITSSL_ERR_LAUNCH;
   }
-  *done = true;
+  done->store(true, std::memory_order_relaxed);
   return VITSSL_OK;
 }
 
-// 2 (default): sequences of more than 128 tokens run the persistent forward with 8 waves x two query tiles; 1: 16 waves x one
-// query tile (same speed within 1-2 %, a few spilled registers at N > 224); 0: the two-workgroups-per-CU kernel
-// (VITSSL_ATTN_FWD_PERSIST, developer knob for A/B timing)
-int attn_fwd_persist() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("VITSSL_ATTN_FWD_PERSIST");
-    v = e ? atoi(e) : 2;
-  }
-  return v;
+// 1 (default): sequences of more than 128 tokens run the persistent forward (8 waves x two query tiles, next item's K / V prefetched);
+// 0: the two-workgroups-per-CU kernel that shorter sequences always use (VITSSL_ATTN_FWD_PERSIST; exercised by tests/test_gpu_knobs.py)
+bool attn_fwd_persist() {
+  static VsEnvInt knob;
+  return knob.get("VITSSL_ATTN_FWD_PERSIST", 1) != 0;
 }
 
 template <int NS>
@@ -1523,87 +1281,61 @@ int launch_fwd(const bf16_t* qkv, bf16_t* out, float* lse, float* probs, int B, 
                unsigned char* out8 = nullptr) {
   if constexpr (NS >= 5) {
     if (attn_fwd_persist()) {
-      static bool done_p1 = false, done_p2 = false;
-      const int lds_p = 4 * NS * 32 * ROWB + 16 * 2048;   // two (K, V) tile pairs + a 2 KiB output window per wave (16 waves at most)
+      static VsOnce done_p{false};
+      const int lds_p = 4 * NS * 32 * ROWB + 8 * 2048;   // two (K, V) tile pairs + a 2 KiB output window per wave
       const int nitems = B * H;
-      const int grid = nitems < attn_cu_count() ? nitems : attn_cu_count();
-      if (attn_fwd_persist() == 2) {                   // 8 waves x two query tiles
-        if (int rc = ensure_lds(attn_fwd_pers_kernel<NS, 2>, lds_p, &done_p2, "attn_fwd_pers")) return rc;
-        hipLaunchKernelGGL((attn_fwd_pers_kernel<NS, 2>), dim3(grid), dim3(512), lds_p, s, qkv, out, lse, probs, N, H, nitems, out8);
-      } else {                                         // 16 waves x one query tile (A/B)
-        if (int rc = ensure_lds(attn_fwd_pers_kernel<NS, 1>, lds_p, &done_p1, "attn_fwd_pers")) return rc;
-        hipLaunchKernelGGL((attn_fwd_pers_kernel<NS, 1>), dim3(grid), dim3(1024), lds_p, s, qkv, out, lse, probs, N, H, nitems, out8);
-      }
+      const int cus = attn_cu_count();
+      const int grid = nitems < cus ? nitems : cus;
+      if (int rc = ensure_lds(attn_fwd_pers_kernel<NS, 2>, lds_p, &done_p, "attn_fwd_pers")) return rc;
+      g_last_attn_fwd_grid.store(grid, std::memory_order_relaxed);
+      hipLaunchKernelGGL((attn_fwd_pers_kernel<NS, 2>), dim3(grid), dim3(512), lds_p, s, qkv, out, lse, probs, N, H, nitems, out8);
       VS_CHECK_LAUNCH("attn_fwd_pers");
       return VITSSL_OK;
     }
   }
-  static bool done = false;
+  static VsOnce done{false};
   const int lds = 2 * NS * 32 * ROWB;
   constexpr int NW = NS <= 2 ? 2 : 4;
   if (int rc = ensure_lds(attn_fwd_kernel<NS, NW>, lds, &done, "attn_fwd")) return rc;
   const int per_cu = lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3);
+  const int cus = attn_cu_count();
+  g_last_attn_fwd_grid.store(B * H, std::memory_order_relaxed);
   hipLaunchKernelGGL((attn_fwd_kernel<NS, NW>), dim3(B * H), dim3(64 * NW), lds, s, qkv, out, lse, probs, N, H,
-                     attn_cu_count() * per_cu, B * H > 2 * attn_cu_count() * per_cu ? attn_stagger_ticks(0) : 0, out8);
+                     cus * per_cu, B * H > 2 * cus * per_cu ? attn_stagger_ticks(0) : 0, out8);
   VS_CHECK_LAUNCH("attn_fwd");
   return VITSSL_OK;
 }
 
-// VITSSL_ATTN_BWD=split selects the two-launch backward (developer knob for A/B timing)
-bool attn_bwd_split() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("VITSSL_ATTN_BWD");
-    v = (e && !strcmp(e, "split")) ? 1 : 0;
-  }
-  return v == 1;
-}
-
-// 1 (default): sequences of more than 128 tokens run the fused backward with the pipelined prologue; 0: attn_bwd_fused_kernel
-// (VITSSL_ATTN_BWD_PIPE, developer knob for A/B timing)
+// 1 (default): sequences of more than 128 tokens run the fused backward with the pipelined prologue; 0: attn_bwd_fused_kernel, which
+// shorter sequences always use (VITSSL_ATTN_BWD_PIPE; exercised by tests/test_gpu_knobs.py)
 bool attn_bwd_pipe() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("VITSSL_ATTN_BWD_PIPE");
-    v = e ? atoi(e) : 1;
-  }
-  return v != 0;
+  static VsEnvInt knob;
+  return knob.get("VITSSL_ATTN_BWD_PIPE", 1) != 0;
 }
 
 template <int NS>
-int launch_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, float* delta, bf16_t* dqkv, int B,
+int launch_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv, int B,
                int N, int H, hipStream_t s, unsigned char* dq8 = nullptr, const float* qscale = nullptr, float* qamax = nullptr) {
+  const int cus = attn_cu_count();
   if constexpr (NS >= 5) {
-    if ((!attn_bwd_split() || dq8) && attn_bwd_pipe()) {
-      static bool done_p = false;
+    if (attn_bwd_pipe()) {
+      static VsOnce done_p{false};
       const int lds_p = 3 * NS * 32 * ROWB + 2 * 32 * (NS * 64 + 16) + 2 * NS * 32 * 4 + 3 * 32 * ROWB;
       if (int rc = ensure_lds(attn_bwd_pipe_kernel<NS>, lds_p, &done_p, "attn_bwd_pipe")) return rc;
       hipLaunchKernelGGL((attn_bwd_pipe_kernel<NS>), dim3(B * H), dim3(512), lds_p, s, qkv, out, dout, lse, dqkv, N, H,
-                         attn_cu_count(), B * H > 2 * attn_cu_count() ? attn_stagger_ticks(1) : 0, dq8, qscale, qamax);
+                         cus, B * H > 2 * cus ? attn_stagger_ticks(1) : 0, dq8, qscale, qamax);
       VS_CHECK_LAUNCH("attn_bwd_pipe");
       return VITSSL_OK;
     }
   }
-  if (!attn_bwd_split() || dq8) {
-    static bool done_f = false;
-    constexpr int NW = NS <= 2 ? 2 : (NS <= 4 ? 4 : 8);
-    const int lds_f = 3 * NS * 32 * ROWB + 2 * 32 * (NS * 64 + 16) + 2 * NS * 32 * 4;
-    if (int rc = ensure_lds(attn_bwd_fused_kernel<NS, NW>, lds_f, &done_f, "attn_bwd_fused")) return rc;
-    const int per_cu = lds_f > 80 * 1024 ? 1 : 2;
-    hipLaunchKernelGGL((attn_bwd_fused_kernel<NS, NW>), dim3(B * H), dim3(64 * NW), lds_f, s, qkv, out, dout, lse, dqkv, N, H,
-                       attn_cu_count() * per_cu, B * H > 2 * attn_cu_count() * per_cu ? attn_stagger_ticks(1) : 0, dq8, qscale, qamax);
-    VS_CHECK_LAUNCH("attn_bwd_fused");
-    return VITSSL_OK;
-  }
-  static bool done_kv = false, done_q = false;
-  const int lds_q = 2 * NS * 32 * ROWB;
-  if (int rc = ensure_lds(attn_bwd_dq_kernel<NS>, lds_q, &done_q, "attn_bwd_dq")) return rc;
-  hipLaunchKernelGGL(attn_bwd_dq_kernel<NS>, dim3(B * H), dim3(256), lds_q, s, qkv, out, dout, lse, delta, dqkv, N, H);
-  VS_CHECK_LAUNCH("attn_bwd_dq");
-  const int lds_kv = 2 * NS * 32 * ROWB + 2 * NS * 32 * 4;
-  if (int rc = ensure_lds(attn_bwd_dkv_kernel<NS>, lds_kv, &done_kv, "attn_bwd_dkv")) return rc;
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel<NS>, dim3(B * H), dim3(512), lds_kv, s, qkv, dout, lse, delta, dqkv, N, H);
-  VS_CHECK_LAUNCH("attn_bwd_dkv");
+  static VsOnce done_f{false};
+  constexpr int NW = NS <= 2 ? 2 : (NS <= 4 ? 4 : 8);
+  const int lds_f = 3 * NS * 32 * ROWB + 2 * 32 * (NS * 64 + 16) + 2 * NS * 32 * 4;
+  if (int rc = ensure_lds(attn_bwd_fused_kernel<NS, NW>, lds_f, &done_f, "attn_bwd_fused")) return rc;
+  const int per_cu = lds_f > 80 * 1024 ? 1 : 2;
+  hipLaunchKernelGGL((attn_bwd_fused_kernel<NS, NW>), dim3(B * H), dim3(64 * NW), lds_f, s, qkv, out, dout, lse, dqkv, N, H,
+                     cus * per_cu, B * H > 2 * cus * per_cu ? attn_stagger_ticks(1) : 0, dq8, qscale, qamax);
+  VS_CHECK_LAUNCH("attn_bwd_fused");
   return VITSSL_OK;
 }
 
@@ -1635,6 +1367,8 @@ extern "C" int vitssl_debug_attn_stamps(void* buf) {
 }
 #endif
 
+extern "C" int vitssl_debug_last_attn_fwd_grid(void) { return g_last_attn_fwd_grid.load(std::memory_order_relaxed); }
+
 extern "C" int vitssl_attn_fwd(const void* qkv, void* out, float* lse, float* probs, int B, int N, int H, int dh,
                                void* stream) {
   VS_CHECK_ARG(qkv && out && lse, "attn_fwd: null pointer");
@@ -1655,10 +1389,11 @@ extern "C" int vitssl_attn_fwd_fp8(const void* qkv, void* out, void* out_fp8, fl
 
 extern "C" int vitssl_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                                float* delta_ws, int B, int N, int H, int dh, void* stream) {
-  VS_CHECK_ARG(qkv && out && dout && lse && dqkv && delta_ws, "attn_bwd: null pointer");
+  (void)delta_ws;   // kept in the signature for ABI stability: the fused kernels compute rowsum(dO * O) in their prologue
+  VS_CHECK_ARG(qkv && out && dout && lse && dqkv, "attn_bwd: null pointer");
   if (int rc = check_attn_shape("attn_bwd", B, N, H, dh)) return rc;
   hipStream_t s = (hipStream_t)stream;
-#define VS_CALL(NS) launch_bwd<NS>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, delta_ws, (bf16_t*)dqkv, B, N, H, s)
+#define VS_CALL(NS) launch_bwd<NS>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, B, N, H, s)
   VS_NS_SWITCH((N + 31) / 32, VS_CALL)
 #undef VS_CALL
 }
@@ -1668,7 +1403,7 @@ extern "C" int vitssl_attn_bwd_fp8(const void* qkv, const void* out, const void*
   VS_CHECK_ARG(qkv && out && dout && lse && dqkv_fp8, "attn_bwd_fp8: null pointer");   // dqkv (bf16) may be NULL
   if (int rc = check_attn_shape("attn_bwd_fp8", B, N, H, dh)) return rc;
   hipStream_t s = (hipStream_t)stream;
-#define VS_CALL(NS) launch_bwd<NS>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, nullptr, (bf16_t*)dqkv, B, N, H, s, \
+#define VS_CALL(NS) launch_bwd<NS>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, B, N, H, s, \
                                    (unsigned char*)dqkv_fp8, qscale, qamax)
   VS_NS_SWITCH((N + 31) / 32, VS_CALL)
 #undef VS_CALL

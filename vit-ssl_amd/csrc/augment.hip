@@ -318,14 +318,14 @@ extern "C" int vitssl_aug_color_u8(uint8_t* img, const int32_t* iparams, const f
   VS_CHECK_ARG(img && iparams && fparams && B > 0 && S > 0, "aug_color: bad args");
   const int bytes = S * S * 3;
   VS_CHECK_ARG(bytes % 4 == 0 && bytes <= 150 * 1024, "aug_color: view %dx%d does not fit the 150 KiB LDS image (S <= 224, S even)", S, S);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static VsOnce attr_done{false};
+  if (!attr_done.load(std::memory_order_relaxed)) {
     hipError_t e = hipFuncSetAttribute((const void*)aug_color_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (e != hipSuccess) {
       vitssl_set_error("aug_color: cannot raise dynamic LDS: %s", hipGetErrorString(e));
       return VITSSL_ERR_LAUNCH;
     }
-    attr_done = true;
+    attr_done.store(true, std::memory_order_relaxed);
   }
   hipLaunchKernelGGL(aug_color_kernel, dim3(B), dim3(1024), bytes, (hipStream_t)stream, img, iparams, fparams, S);
   VS_CHECK_LAUNCH("aug_color");

@@ -1,9 +1,12 @@
 // Shared device/host helpers for libvitssl_hip (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <limits.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include "../../include/vitssl_hip.h"
 
 // ---------------------------------------------------------------- error plumbing
@@ -12,6 +15,37 @@ void vitssl_set_error(const char* fmt, ...);
 // (default 0).  A collective library's kernels cannot co-reside with those workgroups (they take the whole register
 // file and 129 KiB of LDS of their CU), so under data parallelism a few CUs can be left to the all-reduce.
 int vitssl_persistent_cus(void);
+
+// ---------------------------------------------------------------- host-side knob caches
+// Entry points run on the Python main thread AND on autograd's backward thread (include/vitssl_hip.h promises re-entrancy): the
+// per-process caches of environment knobs and of "attribute already set" flags are atomics, never plain statics.  A knob is
+// read from the environment once; two threads racing through the first read store the same value.
+struct VsEnvInt {
+  std::atomic<int> v{INT_MIN};
+  int get(const char* name, int dflt) {
+    int x = v.load(std::memory_order_relaxed);
+    if (x == INT_MIN) {
+      const char* e = getenv(name);
+      x = e ? (int)strtol(e, nullptr, 0) : dflt;
+      if (x == INT_MIN) x = dflt;
+      v.store(x, std::memory_order_relaxed);
+    }
+    return x;
+  }
+};
+struct VsEnvMilli {   // a float knob, cached as thousandths
+  std::atomic<int> v{INT_MIN};
+  float get(const char* name, float dflt) {
+    int x = v.load(std::memory_order_relaxed);
+    if (x == INT_MIN) {
+      const char* e = getenv(name);
+      x = (int)((e ? atof(e) : (double)dflt) * 1000.0 + 0.5);
+      v.store(x, std::memory_order_relaxed);
+    }
+    return (float)x * 1e-3f;
+  }
+};
+typedef std::atomic<bool> VsOnce;   // "hipFuncSetAttribute already done" flags: idempotent work, so relaxed loads / stores suffice
 
 #define VS_CHECK_ARG(cond, ...)            \
   do {                                     \
@@ -98,7 +132,8 @@ __device__ __forceinline__ float wave_max(float v) {
 // and within-group products, cross-key correlation) on the NumPy restatement, and the GPU test compares the kernels'
 // masks with that restatement bit for bit.
 struct DropKey {
-  unsigned k0, k1;
+  unsigned k0, k1, k2;
+  unsigned m1;         // first multiplier of word a: the odd number 0x2c1b3c6d ^ (k1 << 1)
   unsigned thr;        // keep iff u16 (unsigned view) >= thr ... kept for the exported-mask helper and p == 0 tests
   int thr_s;           // thr - 32768: keep iff (signed 16-bit view) >= thr_s
   unsigned tm1_pair;   // (thr_s - 1) & 0xffff in both halves: operand of the packed compare
@@ -113,6 +148,10 @@ __host__ __device__ inline DropKey make_drop_key(vitssl_dropout_t d) {
   s ^= s >> 32;
   k.k0 = (unsigned)s;
   k.k1 = (unsigned)(s >> 32);
+  unsigned long long t2 = s * 0x94D049BB133111EBull;
+  t2 ^= t2 >> 31;
+  k.k2 = (unsigned)(t2 >> 16);
+  k.m1 = (0x2c1b3c6du ^ (k.k1 << 1)) | 1u;
   float p = d.p;
   if (!(p > 0.f)) p = 0.f;
   unsigned t = (unsigned)(p * 65536.0f + 0.5f);
@@ -131,10 +170,14 @@ constexpr unsigned DROP_C0 = 0x9E3779B1u;   // counter multiplier (so that the m
 // tile form it with one add per group from per-row and per-column terms (drop_a0_row / drop_a0_col).
 __device__ __forceinline__ unsigned drop_a0(const DropKey& k, unsigned g) { return g * DROP_C0 + k.k0; }
 
+// Round 4: the key enters word a as well (its first multiplier is key-dependent and k2 is xored in between the two multiplies;
+// same instruction count: the multiplier is a scalar operand either way, the xor fuses into v_xor3_b32).  Before, word a was a
+// fixed bijection of g * C0 + k0, so the a-streams of any two (seed, site) keys were ONE 2^32-long sequence read at different
+// offsets (advisor finding; tests/test_dropout_stream.py::test_streams_of_different_keys_are_not_shifted_copies).
 __device__ __forceinline__ u32x2 drop_words_a0(const DropKey& k, unsigned a) {
   a ^= a >> 15;
-  a *= 0x2c1b3c6du;
-  a ^= a >> 12;
+  a *= k.m1;
+  a = a ^ (a >> 12) ^ k.k2;
   a *= 0x297a2d39u;
   a ^= a >> 15;
   unsigned b = (a ^ k.k1) * 0xc2b2ae35u;

@@ -451,11 +451,18 @@ extern "C" int vitssl_weightnorm_bwd(const float* dw, const float* g, const floa
   return VITSSL_OK;
 }
 
-extern "C" int vitssl_dino_loss(const float* teacher, const float* student, const float* center, float* t_ws, float* loss_sum,
-                                void* dstudent_bf16, int G, int V, int B, int K, float teacher_temp, float student_temp,
-                                float gscale, void* stream) {
+extern "C" int64_t vitssl_dino_loss_workspace_floats(int G, int B, int K) {
+  if (G <= 0 || B <= 0 || K <= 0) return 0;
+  return (int64_t)B * K + VITSSL_DINO_TWS_EXTRA((int64_t)G, (int64_t)B);
+}
+
+extern "C" int vitssl_dino_loss(const float* teacher, const float* student, const float* center, float* t_ws, int64_t t_ws_floats,
+                                float* loss_sum, void* dstudent_bf16, int G, int V, int B, int K, float teacher_temp,
+                                float student_temp, float gscale, void* stream) {
   VS_CHECK_ARG(teacher && student && center && t_ws && loss_sum, "dino_loss: null pointer");
   VS_CHECK_ARG(G > 0 && V > 0 && B > 0 && K > 0 && K % 4 == 0, "dino_loss: K=%d must be a positive multiple of 4", K);
+  VS_CHECK_ARG(t_ws_floats >= vitssl_dino_loss_workspace_floats(G, B, K), "dino_loss: scratch of %lld floats, %lld needed (vitssl_dino_loss_workspace_floats)",
+               (long long)t_ws_floats, (long long)vitssl_dino_loss_workspace_floats(G, B, K));
   VS_CHECK_ARG(teacher_temp > 0.f && student_temp > 0.f, "dino_loss: temperatures must be positive");
   hipStream_t s = (hipStream_t)stream;
   const int nv = (K % 4096 == 0) ? K / 4096 : 0;

@@ -13,4 +13,4 @@ void vitssl_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* vitssl_last_error(void) { return g_err; }
-extern "C" int vitssl_version(void) { return 1; }
+extern "C" int vitssl_version(void) { return 2; }   // 2: vitssl_dino_loss takes the size of its scratch

@@ -153,7 +153,6 @@ struct NtParams {
   int k_chunk;   // split-K: K elements per blockIdx.y slice (0 = no split)
   int stagger;   // ping-pong kernel: estimated time of one output tile in 100 MHz ticks (0 = no start-up stagger)
   int esz;       // operand element size in bytes: 2 = bf16, 1 = fp8 e4m3 (ping-pong kernel only)
-  long long m_base;   // row of the whole problem that this launch's row 0 is (a problem split over two launches): dropout index only
   const float* alpha;   // fp8 operands: device scalar multiplied into the accumulators (product of the dequantisation scales), or NULL
   void* out2;    // fp8 operands: optional e4m3 image of out1 (EPI_GELU) / of out0 (EPI_DGELU) = the next GEMM's A operand, or NULL
   const float* alpha2;  // second device scalar multiplied into the accumulators (1 / scale of a scaled gradient operand), or NULL
@@ -454,7 +453,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
   const unsigned a0rowstep = 16u * (unsigned)(p.N >> 2) * DROP_C0;
   unsigned a0row = 0;
   if (DROPS && p.drop_on)
-    a0row = drop_a0(p.dk, (unsigned)(m0 + wm * CFG::WROWS + (lane & 15) + p.m_base) * (unsigned)(p.N >> 2));
+    a0row = drop_a0(p.dk, (unsigned)(m0 + wm * CFG::WROWS + (lane & 15)) * (unsigned)(p.N >> 2));
   // GELU: the dropout scale is folded into the two constants of gelu_both_scaled
   const float gelu_hs = (DROPS && p.drop_on) ? 0.5f * p.dk.scale : 0.5f;
   const float gelu_cs = (DROPS && p.drop_on) ? 0.3989422804014327f * p.dk.scale : 0.3989422804014327f;
@@ -965,12 +964,17 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MIN_WAVES_PER_SIMD) void gemm_nt
 // lower bound of the epilogue's operations per wave (a smaller count only waits longer).
 // Past the last tile the stream issues out-of-range DMA (zero fill, no memory traffic) so every
 // count stays uniform.
-template <int EPI, int MI>
+template <int EPI, int MI, bool F8>
 constexpr int nt_epi_vmem_ops() {
-  // unconditional buffer loads + stores per wave in nt_epilogue (wide form; the narrow form has more)
+  // LOWER bound of the buffer loads + stores per wave in nt_epilogue (a smaller count only waits longer; a larger one would let
+  // the first K-tile after the epilogue read a staging unit that has not landed).  bf16 operands: GELU = g' + a images (2 + 2 per
+  // row tile), DGELU = g' loads + the bf16 image (2 + 2).  fp8 operands: the bf16 `a` image (GELU) / the bf16 dGELU image are
+  // optional at launch time, so only g' stores (GELU: 2) or g' loads (DGELU: 2) plus the one e4m3 store are certain: 3 per row tile
+  // (round-3 advisor finding: 4 was counted).
   if (NT_ABLATE != 0) return 0;
   return EPI == VITSSL_EPI_BF16 ? 2 * MI
-         : (EPI == VITSSL_EPI_GELU || EPI == VITSSL_EPI_DGELU || EPI == VITSSL_EPI_F32) ? 4 * MI
+         : (EPI == VITSSL_EPI_GELU || EPI == VITSSL_EPI_DGELU) ? (F8 ? 3 * MI : 4 * MI)
+         : EPI == VITSSL_EPI_F32 ? 4 * MI
          : EPI == VITSSL_EPI_RESID ? 8 * MI
          : 0;
 }
@@ -1295,7 +1299,7 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_nt_pp_kernel(NtParams p)
   wait_vmcnt_exact<8>();                               // B0, A0 of K-tile 0 have landed
   section();
 
-  constexpr int S = nt_epi_vmem_ops<EPI, MI>();
+  constexpr int S = nt_epi_vmem_ops<EPI, MI, F8>();
   constexpr int NW_POST = (8 + S) > 63 ? 63 : (8 + S);
   int buf = 0;
 #ifdef VITSSL_NT_STAMPS
@@ -1353,45 +1357,38 @@ void nt_note_grid(int grid);   // remembers the workgroup count of the last ping
 
 // 1 (default): 8-wave BK = 64 tiles run the ping-pong kernel; 0: the two-phase loop (VITSSL_NT_PP, developer knob)
 int nt_pp_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("VITSSL_NT_PP");
-    v = e ? atoi(e) : 1;
-  }
-  return v;
+  static VsEnvInt knob;
+  return knob.get("VITSSL_NT_PP", 1);
 }
 
 template <int EPI, typename CFG, bool F8 = false>
 int launch_pp(NtParams p, hipStream_t s) {
   constexpr int LDS = 2 * CFG::BUF_BYTES + 1024 + ((EPI == VITSSL_EPI_GELU && NT_ABLATE == 0 && NT_GELU_LUT) ? GLUT_BYTES : 0);
-  static bool attr_done = false;  // idempotent; a benign race sets the same value
-  if (!attr_done) {
+  static VsOnce attr_done{false};
+  if (!attr_done.load(std::memory_order_relaxed)) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, CFG, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       vitssl_set_error("gemm_nt: cannot raise dynamic LDS to %d: %s", LDS, hipGetErrorString(e));
       return VITSSL_ERR_LAUNCH;
     }
-    attr_done = true;
+    attr_done.store(true, std::memory_order_relaxed);
   }
   const long long ntiles = (long long)p.tiles_m * p.tiles_n;
   const long long slots = cu_count();
   const long long grid = ntiles < slots ? ntiles : slots;
   // tile-time estimate for the start-up stagger (us): K loop ~1.45 us per 256-row K-tile + an uncontended epilogue
-  static float stagger_scale = -1.f;
-  if (stagger_scale < 0.f) {
-    const char* e = getenv("VITSSL_NT_STAGGER");       // developer knob: scale of the window, 0 = off
+  // VITSSL_NT_STAGGER (developer knob): scale of the window, 0 = off
+  static VsEnvMilli stagger_knob;
+  {
     // Round 2 measured this time-neutral: in the accumulator layout a CU's stores were bound inside the CU (55 GB/s) whether or not
     // the other CUs stored at the same moment.  With line-shaped epilogue accesses (NT_LDS_T) a CU alone stores 180+ GB/s but only
     // ~55 when all 256 burst together, so spreading the epilogues now pays: interleaved A/B, M = 50176: dGELU 281 -> 262 us
     // (N = 3072, K = 768), residual 241 -> 231 (K = 3072), plain stores -1.5..-3 %, never slower; whole step 34.29 -> 34.05 ms.
-    stagger_scale = e ? (float)atof(e) : NT_STAGGER_DEFAULT;
   }
+  const float stagger_scale = stagger_knob.get("VITSSL_NT_STAGGER", NT_STAGGER_DEFAULT);
   // which epilogues stagger (bit = VITSSL_EPI_* value; VITSSL_NT_STAGGER_EPIS overrides): see NT_STAGGER_EPIS_DEFAULT
-  static int stagger_mask = -1;
-  if (stagger_mask < 0) {
-    const char* e = getenv("VITSSL_NT_STAGGER_EPIS");
-    stagger_mask = e ? (int)strtol(e, nullptr, 0) : NT_STAGGER_EPIS_DEFAULT;
-  }
+  static VsEnvInt stagger_mask_knob;
+  const int stagger_mask = stagger_mask_knob.get("VITSSL_NT_STAGGER_EPIS", NT_STAGGER_EPIS_DEFAULT);
   const float epi_us = EPI == VITSSL_EPI_BF16 ? 2.f : EPI == VITSSL_EPI_GELU ? 7.f : EPI == VITSSL_EPI_DGELU ? 5.f
                        : EPI == VITSSL_EPI_RESID ? 8.f : 4.f;
   const float tile_us = (float)(p.K * p.esz / 128) * 1.45f * (float)CFG::MI / 8.f + epi_us;
@@ -1404,24 +1401,21 @@ int launch_pp(NtParams p, hipStream_t s) {
 
 template <int EPI, typename CFG>
 int launch_cfg(NtParams p, hipStream_t s) {
-  static bool attr_done = false;  // idempotent; a benign race sets the same value
-  if (!attr_done && CFG::LDS_BYTES > 48 * 1024) {
+  static VsOnce attr_done{false};
+  if (!attr_done.load(std::memory_order_relaxed) && CFG::LDS_BYTES > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, CFG>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        CFG::LDS_BYTES);
     if (e != hipSuccess) {
       vitssl_set_error("gemm_nt: cannot raise dynamic LDS to %d: %s", CFG::LDS_BYTES, hipGetErrorString(e));
       return VITSSL_ERR_LAUNCH;
     }
-    attr_done = true;
+    attr_done.store(true, std::memory_order_relaxed);
   }
   p.tiles_m = (int)ceil_div64(p.M, CFG::BM);
   p.tiles_n = (int)ceil_div64(p.N, CFG::BN);
   const int want = (int)((2 * 1024 * 1024) / ((long long)CFG::BN * p.K * p.esz));   // panels of a group <= ~2 MiB of L2
-  static int group_knob = -1;                          // VITSSL_NT_GROUPN: force the raster group width (developer knob)
-  if (group_knob < 0) {
-    const char* e = getenv("VITSSL_NT_GROUPN");
-    group_knob = e ? atoi(e) : 0;
-  }
+  static VsEnvInt group_env;                           // VITSSL_NT_GROUPN: force the raster group width (developer knob)
+  const int group_knob = group_env.get("VITSSL_NT_GROUPN", 0);
   if (group_knob > 0) p.group_n = group_knob < p.tiles_n ? group_knob : p.tiles_n;
   else if (p.tiles_n <= 4) p.group_n = p.tiles_n;
   else if (want <= 2) p.group_n = 2;
@@ -1452,11 +1446,8 @@ int launch_cfg(NtParams p, hipStream_t s) {
   // is 0.2-0.5 ms slower persistent; with K = 384 (ViT-S: 6 K-steps per tile, the fixed
   // per-tile cost dominates) the step drops 21.75 -> 20.83 ms.  Default: persistent for
   // K <= 512 only; VITSSL_NT_PERSIST=0/1 forces it (developer knob).
-  static int knob = -2;
-  if (knob == -2) {
-    const char* e = getenv("VITSSL_NT_PERSIST");
-    knob = e ? atoi(e) : -1;
-  }
+  static VsEnvInt persist_env;
+  const int knob = persist_env.get("VITSSL_NT_PERSIST", -1);
   const bool persist = knob >= 0 ? knob != 0 : p.K <= 512;
   const long long ntiles = (long long)p.tiles_m * p.tiles_n;
   long long grid = ntiles;
@@ -1472,12 +1463,8 @@ int launch_cfg(NtParams p, hipStream_t s) {
 
 // 0 = auto, 1 = always BIG, 2 = always SMALL, 3 = always 192x256 (VITSSL_NT_TILE, developer knob)
 int nt_tile_override() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("VITSSL_NT_TILE");
-    v = e ? atoi(e) : 0;
-  }
-  return v;
+  static VsEnvInt knob;
+  return knob.get("VITSSL_NT_TILE", 0);
 }
 
 // Split-K for fp32 outputs whose grid cannot fill the chip but whose contraction is long
@@ -1538,61 +1525,9 @@ int launch_nt(const NtParams& p, hipStream_t s) {
   double best = c256;
   if (c192 < 0.9 * c256 && c192 <= c224) best = c192;
   else if (c224 < 0.95 * c256) best = c224;
-  // Two launches over disjoint row ranges: the first fills whole tile rounds with one tile height, the second
-  // finishes the remaining rows in ONE round with another height, so no round runs with most CUs idle
-  // (M = 50176, N = 768: 672 tiles of 224 rows = 2.6 rounds at cost 2.7; 2 full rounds of 192-row tiles + one
-  // round of 224-row tiles cost 2 x 0.78 + 0.9 = 2.46).  Row ranges only move base pointers; the dropout
-  // stream is indexed by the row of the whole problem (m_base).
-  if constexpr (EPI != VITSSL_EPI_EMBED && EPI != EPI_F32_SPLITK) {
-    // Default OFF: measured 36.95 / 36.88 -> 36.82 / 36.83 ms per ViT-B step (0.3 %).  The ping-pong loop is bound by
-    // the bytes it stages, (rows + 256) per K-tile, so a 192-row tile costs 0.875 of a 256-row one, not 0.78 as the
-    // round-1 loop did, and the second launch has its own prologue: most of the tail's 8 % goes back into smaller tiles.
-    static int split_knob = -1;                          // VITSSL_NT_ROWSPLIT=1 enables (developer knob)
-    if (split_knob < 0) {
-      const char* e = getenv("VITSSL_NT_ROWSPLIT");
-      split_knob = e ? atoi(e) : 0;
-    }
-    static const int heights[3] = {256, 224, 192};
-    static const double costs[3] = {1.0, 0.90, 0.78};
-    int bx = -1, by = -1;
-    long long brows = 0;
-    double bcost = best * 0.97;                          // must beat the single launch by 3 %
-    if (split_knob && p.k_chunk == 0) {
-      for (int x = 0; x < 3; ++x) {
-        const long long per_round = slots / tn;          // tile rows of height x per full round
-        if (per_round < 1) continue;
-        const long long rounds = (p.M / heights[x]) / per_round;   // full rounds of x-tiles that fit
-        for (long long r = rounds; r >= 1 && r >= rounds - 1; --r) {
-          const long long rows_x = r * per_round * heights[x];
-          const long long rest = p.M - rows_x;
-          if (rest <= 0) continue;
-          for (int y = 0; y < 3; ++y) {
-            if (ceil_div64(rest, heights[y]) * tn > slots) continue;
-            const double c = (double)r * costs[x] + costs[y];
-            if (c < bcost) { bcost = c; bx = x; by = y; brows = rows_x; }
-          }
-        }
-      }
-    }
-    if (bx >= 0) {
-      NtParams a = p, b = p;
-      a.M = brows;
-      b.M = p.M - brows;
-      b.m_base = p.m_base + brows;
-      const long long ea = (long long)p.K * p.esz;
-      b.A = (const bf16_t*)((const char*)p.A + brows * ea);
-      const int e0 = (EPI == VITSSL_EPI_F32 || EPI == VITSSL_EPI_RESID) ? 4 : 2;
-      if (p.out0) b.out0 = (char*)p.out0 + brows * (long long)p.N * e0;   // (fp8 dGELU after calibration: no bf16 image)
-      if (p.out1) b.out1 = (char*)p.out1 + brows * (long long)p.N * 2;
-      if (p.out2) b.out2 = (char*)p.out2 + brows * (long long)p.N;
-      if (p.aux) b.aux = (const char*)p.aux + brows * (long long)p.N * (EPI == VITSSL_EPI_RESID ? 4 : 2);
-      auto go = [&](int h, const NtParams& q) {
-        return h == 0 ? launch_cfg<EPI, NtBig>(q, s) : (h == 1 ? launch_cfg<EPI, NtBig224>(q, s) : launch_cfg<EPI, NtBig192>(q, s));
-      };
-      if (int rc = go(bx, a)) return rc;
-      return go(by, b);
-    }
-  }
+  // (Two launches over disjoint row ranges -- whole rounds of one tile height, then one round of another -- were built and
+  // measured in round 2: 0.3 % of a ViT-B step, because the ping-pong loop is bound by the bytes it stages, (rows + 256) per
+  // K-tile, so the smaller tiles give the tail back; removed in round 4, DESIGN.md section 12b keeps the numbers.)
   if (best == c192 && best != c256) return launch_cfg<EPI, NtBig192>(p, s);
   if (best == c224 && best != c256) return launch_cfg<EPI, NtBig224>(p, s);
   return launch_cfg<EPI, NtBig>(p, s);
@@ -1684,7 +1619,6 @@ static int gemm_nt_entry(const vitssl_gemm_t* g, int esz, const vitssl_fp8_gemm_
   p.k_chunk = 0;
   p.stagger = 0;
   p.esz = esz;
-  p.m_base = 0;
   p.alpha = q ? q->alpha : nullptr;
   p.alpha2 = q ? q->alpha2 : nullptr;
   p.out2 = q ? q->out_fp8 : nullptr;

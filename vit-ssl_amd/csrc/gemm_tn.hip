@@ -895,13 +895,10 @@ extern "C" int vitssl_gemm_bf16_tn(const void* A, const void* B, float* C, int64
   // DINO step, 114 us per such call).  The owner adds into C itself.
   p.direct = p.splits == 1;
   if (p.direct) p.slabs = nullptr;
-  static bool attr_done = false;
-  static int use_pp = -1;                              // VITSSL_TN_PP=0: the two-phase loop (developer knob)
-  if (use_pp < 0) {
-    const char* e = getenv("VITSSL_TN_PP");
-    use_pp = e ? atoi(e) : 1;
-  }
-  if (!attr_done) {
+  static VsOnce attr_done{false};
+  static VsEnvInt pp_env;                              // VITSSL_TN_PP=0: the two-phase loop (developer knob; tests/test_gpu_knobs.py)
+  const int use_pp = pp_env.get("VITSSL_TN_PP", 1);
+  if (!attr_done.load(std::memory_order_relaxed)) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
     if (e == hipSuccess)
       e = hipFuncSetAttribute((const void*)gemm_tn_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
@@ -909,7 +906,7 @@ extern "C" int vitssl_gemm_bf16_tn(const void* A, const void* B, float* C, int64
       vitssl_set_error("gemm_tn: cannot raise dynamic LDS: %s", hipGetErrorString(e));
       return VITSSL_ERR_LAUNCH;
     }
-    attr_done = true;
+    attr_done.store(true, std::memory_order_relaxed);
   }
   hipStream_t s = (hipStream_t)stream;
   if (use_pp)
@@ -934,9 +931,10 @@ namespace {
 // fitted to whole-step measurements with forced split counts (VITSSL_TN_BATCH_SPLITS): ViT-B (108 tiles) 2 splits 33.27 ms,
 // 7: 33.49, 9: 33.91, 3: 35.69; ViT-S (38 tiles) 6 splits 14.35 ms, 13: 14.78, 4: 14.95, 20: 15.21, 8: 15.55.
 // 1 split = every tile has one owner: no partials.
-void tn_batch_plan(long long M, int T, int* splits, int* chunks_per_split, int* rem_chunks, int km = TN_KM) {
+// G = workgroups of the launch = CUs this library may occupy, read ONCE per entry call by the caller (the reserve is mutable process
+// state: vitssl_set_reserved_cus), so that the plan, the workspace requirement and the grid of one launch all follow the same value.
+void tn_batch_plan(long long M, int T, int G, int* splits, int* chunks_per_split, int* rem_chunks, int km = TN_KM) {
   const long long total_chunks = (M + km - 1) / km;
-  const int G = vitssl_persistent_cus();
   const double c_kt = 1.46, c_unit = 9.0, c_part = 0.15;        // us per K-tile of a unit, per unit, per partial tile (see above)
   double best = 1e30;
   int best_s = 1;
@@ -953,11 +951,8 @@ void tn_batch_plan(long long M, int T, int* splits, int* chunks_per_split, int* 
       best_s = (int)sp;
     }
   }
-  static int forced = -1;                                       // VITSSL_TN_BATCH_SPLITS: force the split count (developer knob)
-  if (forced < 0) {
-    const char* e = getenv("VITSSL_TN_BATCH_SPLITS");
-    forced = e ? atoi(e) : 0;
-  }
+  static VsEnvInt forced_env;                                   // VITSSL_TN_BATCH_SPLITS: force the split count (developer knob)
+  const int forced = forced_env.get("VITSSL_TN_BATCH_SPLITS", 0);
   if (forced > 0 && forced <= total_chunks) best_s = forced;
   *chunks_per_split = (int)((total_chunks + best_s - 1) / best_s);
   *splits = (int)((total_chunks + *chunks_per_split - 1) / *chunks_per_split);
@@ -969,11 +964,8 @@ void tn_batch_plan(long long M, int T, int* splits, int* chunks_per_split, int* 
   // box, alternating; helpers sized with c_rem = c_kt): ViT-B 32.90 -> 32.67 ms, but ViT-S 14.17 -> 14.24 and DINO 39.9 -> 40.2
   // where the model promised 7 %: with c_rem = 2.2 us and a 5 % threshold only the ViT-B-like lists use helpers.
   // VITSSL_TN_BATCH_REM=0 turns them off.
-  static int use_rem = -1;
-  if (use_rem < 0) {
-    const char* e = getenv("VITSSL_TN_BATCH_REM");
-    use_rem = e ? atoi(e) : 1;
-  }
+  static VsEnvInt rem_env;
+  const int use_rem = rem_env.get("VITSSL_TN_BATCH_REM", 1);
   const long long mainu = (long long)T * *splits;
   const long long R = G - mainu;
   if (use_rem && mainu <= G && R >= 8) {
@@ -1009,7 +1001,7 @@ extern "C" int64_t vitssl_gemm_tn_batch_workspace_floats(const vitssl_tn_job_t* 
   TnBatchParams p;
   const int T = tn_batch_tiles(jobs, njobs, &p);
   int sp, cps, rem;
-  tn_batch_plan(M, T, &sp, &cps, &rem);
+  tn_batch_plan(M, T, vitssl_persistent_cus(), &sp, &cps, &rem);
   return (sp > 1 || rem > 0) ? (int64_t)(sp + (rem > 0)) * T * TN_T * TN_T : 0;
 }
 
@@ -1040,23 +1032,23 @@ extern "C" int vitssl_gemm_bf16_tn_batch(const vitssl_tn_job_t* jobs, int njobs,
   for (int j = njobs + 1; j <= TN_MAX_JOBS; ++j) p.tile0[j] = T;
   p.njobs = njobs;
   p.M = M;
-  tn_batch_plan(M, T, &p.splits, &p.chunks_per_split, &p.rem_chunks);
+  const long long cus = vitssl_persistent_cus();               // once per launch: plan, workspace check and grid use this value
+  tn_batch_plan(M, T, (int)cus, &p.splits, &p.chunks_per_split, &p.rem_chunks);
   const long long need = (p.splits > 1 || p.rem_chunks > 0) ? (long long)(p.splits + (p.rem_chunks > 0)) * T * TN_T * TN_T : 0;
-  VS_CHECK_ARG(need == 0 || (workspace && workspace_floats >= need), "gemm_tn_batch: workspace of %lld floats needed (vitssl_gemm_tn_batch_workspace_floats)",
-               need);
+  VS_CHECK_ARG(need == 0 || (workspace && workspace_floats >= need), "gemm_tn_batch: workspace of %lld floats needed with %lld CUs available (vitssl_gemm_tn_batch_workspace_floats; the answer\n"
+               "changes with vitssl_set_reserved_cus: query again after changing the reserve)", need, cus);
   p.slots = need ? workspace : nullptr;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static VsOnce attr_done{false};
+  if (!attr_done.load(std::memory_order_relaxed)) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
     if (e != hipSuccess) {
       vitssl_set_error("gemm_tn_batch: cannot raise dynamic LDS: %s", hipGetErrorString(e));
       return VITSSL_ERR_LAUNCH;
     }
-    attr_done = true;
+    attr_done.store(true, std::memory_order_relaxed);
   }
   hipStream_t s = (hipStream_t)stream;
   const long long units = (long long)T * p.splits;
-  const long long cus = vitssl_persistent_cus();
   const unsigned grid = (unsigned)((units < cus && p.rem_chunks == 0) ? units : cus);      // (with a remainder range every CU has work)
   hipLaunchKernelGGL(gemm_tn_batch_kernel, dim3(grid), dim3(TN_THREADS), TN_LDS_BYTES, s, p);
   VS_CHECK_LAUNCH("gemm_tn_batch");
@@ -1096,14 +1088,14 @@ extern "C" int vitssl_gemm_fp8_tn(const void* A8, const void* B8, float* C, int6
   VS_CHECK_ARG(!workspace || p.slabs, "gemm_fp8_tn: workspace too small (%lld < %lld floats)", (long long)workspace_floats, need);
   p.direct = p.splits == 1;
   if (p.direct) p.slabs = nullptr;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static VsOnce attr_done{false};
+  if (!attr_done.load(std::memory_order_relaxed)) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_fp8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
     if (e != hipSuccess) {
       vitssl_set_error("gemm_fp8_tn: cannot raise dynamic LDS: %s", hipGetErrorString(e));
       return VITSSL_ERR_LAUNCH;
     }
-    attr_done = true;
+    attr_done.store(true, std::memory_order_relaxed);
   }
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(gemm_tn_fp8_kernel, dim3(p.tiles1 * p.tiles2 * p.splits), dim3(TN_THREADS), TN_LDS_BYTES, s, p);
@@ -1147,7 +1139,7 @@ extern "C" int64_t vitssl_gemm_fp8_tn_batch_workspace_floats(const vitssl_fp8_tn
   Tn8BatchParams pp;
   const int T = tn8_batch_fill(jobs, njobs, &pp);
   int sp, cps, rem;
-  tn_batch_plan(M, T, &sp, &cps, &rem, TN8_KM);
+  tn_batch_plan(M, T, vitssl_persistent_cus(), &sp, &cps, &rem, TN8_KM);
   return (sp > 1 || rem > 0) ? (int64_t)(sp + (rem > 0)) * T * TN_T * TN_T : 0;
 }
 
@@ -1167,23 +1159,23 @@ extern "C" int vitssl_gemm_fp8_tn_batch(const vitssl_fp8_tn_job_t* jobs, int njo
   TnBatchParams& p = pp.b;
   const int T = tn8_batch_fill(jobs, njobs, &pp);
   p.M = M;
-  tn_batch_plan(M, T, &p.splits, &p.chunks_per_split, &p.rem_chunks, TN8_KM);
+  const long long cus = vitssl_persistent_cus();               // once per launch: plan, workspace check and grid use this value
+  tn_batch_plan(M, T, (int)cus, &p.splits, &p.chunks_per_split, &p.rem_chunks, TN8_KM);
   const long long need = (p.splits > 1 || p.rem_chunks > 0) ? (long long)(p.splits + (p.rem_chunks > 0)) * T * TN_T * TN_T : 0;
   VS_CHECK_ARG(need == 0 || (workspace && workspace_floats >= need),
                "gemm_fp8_tn_batch: workspace of %lld floats needed (vitssl_gemm_fp8_tn_batch_workspace_floats)", need);
   p.slots = need ? workspace : nullptr;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static VsOnce attr_done{false};
+  if (!attr_done.load(std::memory_order_relaxed)) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_fp8_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
     if (e != hipSuccess) {
       vitssl_set_error("gemm_fp8_tn_batch: cannot raise dynamic LDS: %s", hipGetErrorString(e));
       return VITSSL_ERR_LAUNCH;
     }
-    attr_done = true;
+    attr_done.store(true, std::memory_order_relaxed);
   }
   hipStream_t s = (hipStream_t)stream;
   const long long units = (long long)T * p.splits;
-  const long long cus = vitssl_persistent_cus();
   const unsigned grid = (unsigned)((units < cus && p.rem_chunks == 0) ? units : cus);
   hipLaunchKernelGGL(gemm_tn_fp8_batch_kernel, dim3(grid), dim3(TN_THREADS), TN_LDS_BYTES, s, pp);
   VS_CHECK_LAUNCH("gemm_fp8_tn_batch");

@@ -47,6 +47,7 @@ class Fp8Gemm(C.Structure):
 
 EPI_BF16, EPI_F32, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_EMBED = range(6)
 
+ABI_VERSION = 2          # vitssl_version(): 2 = vitssl_dino_loss takes the size of its scratch buffer
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
 # name -> argtypes (restype is always int except the two noted)
@@ -95,7 +96,7 @@ PROTOTYPES = {
     "vitssl_rownorm_bwd": [_vp, _vp, _vp, _vp, _i64, _i, _vp],
     "vitssl_weightnorm_fold": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "vitssl_weightnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
-    "vitssl_dino_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp],
+    "vitssl_dino_loss": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp],
     "vitssl_colsum_f32": [_vp, _vp, _i64, _i, _vp],
     "vitssl_center_ema": [_vp, _vp, _i, _f, _f, _vp],
     "vitssl_set_reserved_cus": [_i],
@@ -130,6 +131,9 @@ def lib():
     l.vitssl_last_error.argtypes = []
     l.vitssl_version.restype = C.c_int
     l.vitssl_version.argtypes = []
+    if l.vitssl_version() != ABI_VERSION:
+        raise VitsslError(f"{LIB_PATH} implements C-ABI version {l.vitssl_version()}, these bindings expect {ABI_VERSION}: "
+                          "rebuild it (python __graft_entry__.py)")
     l.vitssl_gemm_tn_workspace_floats.restype = C.c_int64
     l.vitssl_gemm_tn_workspace_floats.argtypes = [C.c_int64, C.c_int, C.c_int]
     l.vitssl_gemm_tn_batch_workspace_floats.restype = C.c_int64
@@ -138,9 +142,11 @@ def lib():
     l.vitssl_gemm_fp8_tn_batch_workspace_floats.argtypes = [C.POINTER(Fp8TnJob), C.c_int, C.c_int64]
     l.vitssl_gemm_fp8_tn_workspace_floats.restype = C.c_int64
     l.vitssl_gemm_fp8_tn_workspace_floats.argtypes = [C.c_int64, C.c_int, C.c_int]
+    l.vitssl_dino_loss_workspace_floats.restype = C.c_int64
+    l.vitssl_dino_loss_workspace_floats.argtypes = [C.c_int, C.c_int, C.c_int]
     l.vitssl_embed_bwd_workspace_floats.restype = C.c_int64
     l.vitssl_embed_bwd_workspace_floats.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
-    for getter in ("vitssl_get_reserved_cus", "vitssl_debug_last_nt_grid"):
+    for getter in ("vitssl_get_reserved_cus", "vitssl_debug_last_nt_grid", "vitssl_debug_last_attn_fwd_grid"):
         getattr(l, getter).restype = C.c_int
         getattr(l, getter).argtypes = []
     for name, args in PROTOTYPES.items():

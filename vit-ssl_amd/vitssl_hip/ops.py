@@ -532,7 +532,7 @@ def weightnorm_bwd(dw, g, v, inv_vnorm, dg, dv):
 
 def dino_tws_floats(G, B, K):
     """size of vitssl_dino_loss's scratch: [B, K] teacher probabilities + VITSSL_DINO_TWS_EXTRA(G, B) statistics"""
-    return B * K + 8 * G * B
+    return int(L.lib().vitssl_dino_loss_workspace_floats(G, B, K))
 
 
 def dino_loss(teacher, student, center, t_ws, loss_sum, dstudent, G, V, B, K, teacher_temp, student_temp, gscale=1.0):
@@ -544,7 +544,7 @@ def dino_loss(teacher, student, center, t_ws, loss_sum, dstudent, G, V, B, K, te
 
 def _dino_loss(teacher, student, center, t_ws, loss_sum, dstudent, G, V, B, K, teacher_temp, student_temp, gscale=1.0):
     call("vitssl_dino_loss", _chk(teacher, F32, "teacher", (G * B, K)), _chk(student, F32, "student", (V * B, K)),
-         _chk(center, F32, "center"), _chk(t_ws, F32, "t_ws", (dino_tws_floats(G, B, K),)), _chk(loss_sum, F32, "loss_sum", (1,)),
+         _chk(center, F32, "center"), _chk(t_ws, F32, "t_ws"), t_ws.numel(), _chk(loss_sum, F32, "loss_sum", (1,)),
          _opt(dstudent, BF16, "dstudent", (V * B, K)), G, V, B, K, float(teacher_temp), float(student_temp), float(gscale), _stream())
 
 
