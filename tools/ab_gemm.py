@@ -88,6 +88,16 @@ def main():
     torch.manual_seed(0)
     rb = lambda *s: (torch.randn(*s, device=DEV) * 0.5).to(torch.bfloat16)  # noqa: E731
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # stream-K workspace per library (each build has its own registration); SK="1,0" = per variant on / off
+    sk = [v != "0" for v in os.environ.get("SK", ",".join("1" for _ in names)).split(",")]
+    keep = []
+    for lib, on in zip(libs, sk + [True] * len(libs)):
+        if on and hasattr(lib, "vitssl_set_nt_workspace"):
+            lib.vitssl_nt_workspace_bytes.restype = C.c_int64
+            ws = torch.empty(int(lib.vitssl_nt_workspace_bytes()), dtype=torch.uint8, device=DEV)
+            lib.vitssl_set_nt_workspace.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+            assert lib.vitssl_set_nt_workspace(ws.data_ptr(), ws.numel(), st) == 0
+            keep.append(ws)
     print("variants:", " ".join(names), flush=True)
     if os.environ.get("MODE") == "tn":
         return tn_mode(names, libs, M, rounds, iters, st)
@@ -148,6 +158,9 @@ def main():
                 med.append((ts[len(ts) // 2], ts[0]))
             fl = 2.0 * M * N * K
             line = f"nt {M}x{N}x{K:5d} {name:11s}"
+            if hasattr(libs[0], "vitssl_debug_last_nt_streamk"):
+                run(libs[0])
+                line += f" sk{libs[0].vitssl_debug_last_nt_streamk()}"
             for li, (m, lo) in enumerate(med):
                 line += f" | {names[li]} {m:7.1f} us (min {lo:6.1f}) {fl / m / 1e6:6.0f} TF/s x{m / med[0][0]:.3f}"
             print(line, flush=True)
