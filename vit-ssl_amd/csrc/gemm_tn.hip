@@ -780,6 +780,199 @@ __device__ __forceinline__ void tn8_unit(const Tn8Unit& p, char* smem) {
   }
 }
 
+
+// ---- ping-pong form of the e4m3 weight-gradient loop (round 4) ----------------------------------------------------------------
+// Same roles as tn_pp_unit: waves 4-7 (the n1 half w1 = 1 of the tile) run one barrier behind waves 0-3, so on every SIMD one wave is
+// in its 32-MFMA cluster while its partner reads fragments and issues DMA.  One K = 128 MFMA consumes all 128 rows of a K-tile, so
+// the refill units cannot be row halves as in the bf16 loop; they are COLUMN ranges, made separable in LDS:
+//     A_g = columns 128 g .. 128 g + 127 of the A tile (what wave group g multiplies): 128 rows x 128 B, its own 16 KiB region,
+//     B   = the whole B tile (both groups read it): 128 rows x 256 B.
+// LDS: [A_0 buf 0][A_0 buf 1][A_1 buf 0][A_1 buf 1][B buf 0][B buf 1] (both buffers of a region within a ds_read immediate).
+// A_g rows are 128 B, so rows r and r + 1 share a 256-byte bank row; 16-byte chunk c of row r sits at position c ^ fa(r),
+// fa(r) = ((r >> 1) & 3) | ((r >> 5) & 1) << 2: the 32 lanes of a transposed read (rows 8 q + 0..7 and 32 + 8 q + 0..7) then touch
+// 16 distinct 16-byte slots of the bank row (conflict-free), and a DMA instruction fetches 8 rows x one whole 128-byte line.
+// Schedule (group 0 = waves 0-3, group 1 = waves 4-7; K-tile t lives in buffer t & 1):
+//     group 0, LOAD(t): 48 reads of (A_0, B)(t); DMA B(t+1);                lgkmcnt(0); barrier; 32 MFMAs; vmcnt(0); barrier
+//     group 1, LOAD(t): 48 reads of (A_1, B)(t); DMA A_1(t+1), A_0(t+2); vmcnt(8); lgkmcnt(0); barrier; 32 MFMAs; vmcnt(4); barrier
+// A region is refilled by a wave that has passed a barrier BEHIND the lgkmcnt(0) of its last readers (hence the wait in front of the
+// barrier, unlike the bf16 loop), and every wave waits for its own DMA in front of the barrier that precedes the first read of it:
+// B(t+1) (issued before barrier 2t) by the vmcnt(0) in front of barrier 2t+1; A_1(t+1) (issued between barriers 2t and 2t+1) by the
+// vmcnt(4) in front of barrier 2t+2; A_0(t+2) (same place) by the vmcnt(8) of LOAD(t+1), in front of barrier 2t+3 -- group 0 reads
+// it after that barrier.  K-tiles past the unit's range get an empty buffer window (zero fill, no traffic), so counts stay uniform.
+__device__ __forceinline__ int tn8_fa(int row) { return ((row >> 1) & 3) | (((row >> 5) & 1) << 2); }
+
+__device__ __forceinline__ void tn8_pp_unit(const Tn8Unit& p, char* smem) {
+  constexpr int AG = TN8_KM * 128;                     // 16 KiB: one A_g region
+  constexpr int BT = TN8_KM * 256;                     // 32 KiB: the B tile
+  constexpr int B_BASE = 4 * AG;
+  constexpr unsigned OOBV = 0x80000000u;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int w1 = wave >> 2, w2 = wave & 3;
+  const int c1 = p.c1, c2 = p.c2;
+  const long long ch_begin = p.ch_begin;
+  const int nk = p.nk;
+
+  // K-tile t of an operand as a buffer window: rows (ch_begin + t) * 128 .. M - 1 (rows past M read as zero); empty past the range
+  auto window = [&](const unsigned char* base, int ncols, int t) {
+    const long long row0 = (ch_begin + t) * (long long)TN8_KM;
+    const long long rows = t < nk ? p.M - row0 : 0;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + row0 * ncols), 0, (int)(rows * ncols), 0x00020000);
+  };
+  // staging slots: 8 DMA instructions per wave and K-tile.  Group 0: the B tile, slot e = rows 32 w2 + 4 e (+ lane >> 4), chunk
+  // lane & 15 (as tn8_unit).  Group 1: slots 0-3 = A_1, slots 4-7 = A_0, rows 32 w2 + 8 (e & 3) (+ lane >> 3), position lane & 7.
+  unsigned voff[8];
+  int ldsoff[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    if (w1 == 0) {
+      const int r0 = 32 * w2 + 4 * e;
+      const int row = r0 + (lane >> 4);
+      const int sch = (lane & 15) ^ tn8_f(row);
+      voff[e] = c2 + sch * 16 < p.N2 ? (unsigned)(row * (long long)p.N2 + c2 + sch * 16) : OOBV;
+      ldsoff[e] = B_BASE + r0 * 256;
+    } else {
+      const int gsel = e < 4 ? 1 : 0;
+      const int r0 = 32 * w2 + 8 * (e & 3);
+      const int row = r0 + (lane >> 3);
+      const int sc = (lane & 7) ^ tn8_fa(row);
+      const int col = c1 + 128 * gsel + sc * 16;
+      voff[e] = col < p.N1 ? (unsigned)(row * (long long)p.N1 + col) : OOBV;
+      ldsoff[e] = gsel * 2 * AG + r0 * 128;
+    }
+  }
+  auto issue_b = [&](int t, int bufsel) {               // group 0
+    __amdgpu_buffer_rsrc_t rs = window(p.B, p.N2, t);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) tn_dma16(rs, smem + ldsoff[e] + bufsel * BT, voff[e]);
+  };
+  auto issue_a = [&](int t, int bufsel, auto first_c) {  // group 1: slots first .. first + 3
+    constexpr int first = decltype(first_c)::value;
+    __amdgpu_buffer_rsrc_t rs = window(p.A, p.N1, t);
+#pragma unroll
+    for (int e = first; e < first + 4; ++e) tn_dma16(rs, smem + ldsoff[e] + bufsel * AG, voff[e]);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I4 = std::integral_constant<int, 4>;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses (buffer 0, read 0): A_g rows are 128 B (read q adds 8 rows = 1024 B), B rows 256 B (2048 B per read)
+  const unsigned lds0 = (unsigned)(unsigned long long)LDS_PTR(smem);
+  unsigned fragA[8], fragB[4];
+  {
+    const int g = lane >> 4, i16 = lane & 15;
+    const int r0 = 32 * g + (i16 >> 1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fragA[i] = lds0 + w1 * 2 * AG + r0 * 128 + ((i ^ tn8_fa(r0)) << 4) + 8 * (i16 & 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fragB[j] = lds0 + B_BASE + r0 * 256 + (((w2 * 4 + j) ^ tn8_f(r0)) << 4) + 8 * (i16 & 1);
+  }
+  tn_i32x2 rb[4][4], ra[8][4];
+  auto read_frags = [&](auto buf_c) {
+    constexpr int IA = decltype(buf_c)::value * AG, IB = decltype(buf_c)::value * BT;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      tn8_ds_tr<IB>(rb[j][0], fragB[j]);
+      tn8_ds_tr<IB + 2048>(rb[j][1], fragB[j]);
+      tn8_ds_tr<IB + 4096>(rb[j][2], fragB[j]);
+      tn8_ds_tr<IB + 6144>(rb[j][3], fragB[j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      tn8_ds_tr<IA>(ra[i][0], fragA[i]);
+      tn8_ds_tr<IA + 1024>(ra[i][1], fragA[i]);
+      tn8_ds_tr<IA + 2048>(ra[i][2], fragA[i]);
+      tn8_ds_tr<IA + 3072>(ra[i][3], fragA[i]);
+    }
+  };
+  auto mma = [&]() {
+    i32x8 fb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      fb[j] = i32x8{rb[j][0][0], rb[j][0][1], rb[j][1][0], rb[j][1][1], rb[j][2][0], rb[j][2][1], rb[j][3][0], rb[j][3][1]};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const i32x8 fa = {ra[i][0][0], ra[i][0][1], ra[i][1][0], ra[i][1][1], ra[i][2][0], ra[i][2][1], ra[i][3][0], ra[i][3][1]};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb[j], fa, acc[i][j], 0, 0, 0, 0, 0, 0);
+    }
+  };
+  auto ktile = [&](auto buf_c, int t, bool skip_section) {
+    constexpr int bsel = decltype(buf_c)::value;
+    read_frags(buf_c);
+    if (w1 == 0) {
+      issue_b(t + 1, bsel ^ 1);
+    } else {
+      issue_a(t + 1, bsel ^ 1, I0{});                   // A_1(t+1)
+      issue_a(t + 2, bsel, I4{});                       // A_0(t+2)
+      tn_wait_vmcnt<8>();                               // everything older than those two: A_0(t+1) among it
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads are DONE before the barrier: the partner group refills behind it
+    tn_section();
+    mma();
+    if (w1 == 0) tn_wait_vmcnt<0>();                    // B(t+1)
+    else tn_wait_vmcnt<4>();                            // A_1(t+1)
+    if (!skip_section) tn_section();
+  };
+
+  if (nk > 0) {
+    if (w1 == 0) {
+      issue_b(0, 0);
+    } else {
+      issue_a(0, 0, I0{});
+      issue_a(0, 0, I4{});
+      issue_a(1, 1, I4{});
+    }
+    tn_wait_vmcnt<0>();
+    tn_section();
+    if (w1 == 1) tn_section();                         // waves 4-7 run one barrier behind waves 0-3
+    for (int t = 0; t < nk; t += 2) {
+      ktile(I0{}, t, t + 1 == nk && w1 == 1);          // (waves 4-7 leave the stagger at the end)
+      if (t + 1 >= nk) break;
+      ktile(I1{}, t + 1, t + 2 == nk && w1 == 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing zero-fill DMA retired before the LDS is released
+  }
+
+  const float al = (p.alpha ? *p.alpha : 1.0f) * (p.alpha2 ? *p.alpha2 : 1.0f);
+  if (p.mode == 3) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *(f32x4*)(p.dst + (w1 * 128 + i * 16 + (lane & 15)) * TN_T + w2 * 64 + j * 16 + 4 * (lane >> 4)) = acc[i][j] * al;
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int n1 = c1 + w1 * 128 + i * 16 + (lane & 15);
+    if (n1 >= p.N1) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n2 = c2 + w2 * 64 + j * 16 + 4 * (lane >> 4);
+      if (n2 >= p.N2) continue;
+      float* q = p.dst + (long long)n1 * p.N2 + n2;
+      const f32x4 v = acc[i][j] * al;
+      if (p.mode == 0) {
+        *(f32x4*)q = v;
+      } else if (p.mode == 1) {
+        *(f32x4*)q = *(const f32x4*)q + v;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) unsafeAtomicAdd(q + r, v[r]);
+      }
+    }
+  }
+}
+
+template <bool PP>
 __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_fp8_kernel(Tn8Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int ntiles = p.tiles1 * p.tiles2;
@@ -807,7 +1000,8 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_fp8_kernel(Tn8Params p)
   u.mode = p.slabs ? 0 : (p.direct ? 1 : 2);
   u.alpha = p.alpha;
   u.alpha2 = p.alpha2;
-  tn8_unit(u, smem);
+  if constexpr (PP) tn8_pp_unit(u, smem);
+  else tn8_unit(u, smem);
 }
 
 // several e4m3 weight gradients over the same rows in one launch (vitssl_gemm_fp8_tn_batch; see gemm_tn_batch_kernel)
@@ -817,6 +1011,7 @@ struct Tn8BatchParams {
   const float* alpha2[TN_MAX_JOBS];
 };
 
+template <bool PP>
 __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_fp8_batch_kernel(Tn8BatchParams pp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const TnBatchParams& p = pp.b;
@@ -837,7 +1032,8 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_fp8_batch_kernel(Tn8Bat
     u.mode = p.slots ? 3 : 1;
     u.alpha = pp.alpha[j];
     u.alpha2 = pp.alpha2[j];
-    tn8_unit(u, smem);
+    if constexpr (PP) tn8_pp_unit(u, smem);
+    else tn8_unit(u, smem);
     __syncthreads();                                   // every wave is done with the LDS before the next unit's first DMA
   }
 }
@@ -1059,6 +1255,13 @@ extern "C" int vitssl_gemm_bf16_tn_batch(const vitssl_tn_job_t* jobs, int njobs,
   return VITSSL_OK;
 }
 
+// 1 (default): the e4m3 weight gradients run the ping-pong loop (tn8_pp_unit); 0: all eight waves in step (tn8_unit)
+// (VITSSL_TN8_PP, developer knob; tests/test_gpu_knobs.py)
+static int tn8_pp_enabled() {
+  static VsEnvInt knob;
+  return knob.get("VITSSL_TN8_PP", 1);
+}
+
 extern "C" int64_t vitssl_gemm_fp8_tn_workspace_floats(int64_t M, int N1, int N2) {
   if (M <= 0 || N1 <= 0 || N2 <= 0) return 0;
   int t1, t2, sp, cps;
@@ -1090,7 +1293,9 @@ extern "C" int vitssl_gemm_fp8_tn(const void* A8, const void* B8, float* C, int6
   if (p.direct) p.slabs = nullptr;
   static VsOnce attr_done{false};
   if (!attr_done.load(std::memory_order_relaxed)) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_fp8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_fp8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)gemm_tn_fp8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
     if (e != hipSuccess) {
       vitssl_set_error("gemm_fp8_tn: cannot raise dynamic LDS: %s", hipGetErrorString(e));
       return VITSSL_ERR_LAUNCH;
@@ -1098,7 +1303,10 @@ extern "C" int vitssl_gemm_fp8_tn(const void* A8, const void* B8, float* C, int6
     attr_done.store(true, std::memory_order_relaxed);
   }
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(gemm_tn_fp8_kernel, dim3(p.tiles1 * p.tiles2 * p.splits), dim3(TN_THREADS), TN_LDS_BYTES, s, p);
+  if (tn8_pp_enabled())
+    hipLaunchKernelGGL(gemm_tn_fp8_kernel<true>, dim3(p.tiles1 * p.tiles2 * p.splits), dim3(TN_THREADS), TN_LDS_BYTES, s, p);
+  else
+    hipLaunchKernelGGL(gemm_tn_fp8_kernel<false>, dim3(p.tiles1 * p.tiles2 * p.splits), dim3(TN_THREADS), TN_LDS_BYTES, s, p);
   VS_CHECK_LAUNCH("gemm_fp8_tn");
   if (p.slabs) {
     const long long n4 = (long long)N1 * N2 / 4;
@@ -1167,7 +1375,9 @@ extern "C" int vitssl_gemm_fp8_tn_batch(const vitssl_fp8_tn_job_t* jobs, int njo
   p.slots = need ? workspace : nullptr;
   static VsOnce attr_done{false};
   if (!attr_done.load(std::memory_order_relaxed)) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_fp8_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_fp8_batch_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)gemm_tn_fp8_batch_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
     if (e != hipSuccess) {
       vitssl_set_error("gemm_fp8_tn_batch: cannot raise dynamic LDS: %s", hipGetErrorString(e));
       return VITSSL_ERR_LAUNCH;
@@ -1177,7 +1387,10 @@ extern "C" int vitssl_gemm_fp8_tn_batch(const vitssl_fp8_tn_job_t* jobs, int njo
   hipStream_t s = (hipStream_t)stream;
   const long long units = (long long)T * p.splits;
   const unsigned grid = (unsigned)((units < cus && p.rem_chunks == 0) ? units : cus);
-  hipLaunchKernelGGL(gemm_tn_fp8_batch_kernel, dim3(grid), dim3(TN_THREADS), TN_LDS_BYTES, s, pp);
+  if (tn8_pp_enabled())
+    hipLaunchKernelGGL(gemm_tn_fp8_batch_kernel<true>, dim3(grid), dim3(TN_THREADS), TN_LDS_BYTES, s, pp);
+  else
+    hipLaunchKernelGGL(gemm_tn_fp8_batch_kernel<false>, dim3(grid), dim3(TN_THREADS), TN_LDS_BYTES, s, pp);
   VS_CHECK_LAUNCH("gemm_fp8_tn_batch");
   if (p.slots) {
     hipLaunchKernelGGL(tn_batch_reduce_kernel, dim3((unsigned)T * 8u), dim3(256), 0, s, p);
