@@ -528,7 +528,11 @@ __global__ __launch_bounds__(1024 / QT, QT == 1 ? 4 : 2) void attn_fwd_pers_kern
         inv[t] = 1.0f / sum[t];
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m[t] * SCALE + __logf(sum[t])), rl, g == 0 ? (unsigned)q[t] * 4u : OOB, 0, 0);
         if (probs && q[t] < N) {
-          float* pr = probs + (((long long)b * H + h) * N + q[t]) * N;
+          // (the row term is formed HERE: hoisted out of the item loop, its 64-bit lane value was the one spilled register pair of
+          // the NS = 8 instantiation -- in a path only `return_attn` callers take)
+          int qrow = q[t];
+          asm volatile("" : "+v"(qrow));
+          float* pr = probs + (((long long)b * H + h) * N + qrow) * N;
 #pragma unroll
           for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll

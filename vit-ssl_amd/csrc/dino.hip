@@ -301,45 +301,65 @@ __global__ __launch_bounds__(DR_THREADS) void dino_teacher_norm_kernel(const flo
   for (int v = 0; v < NVS; ++v) *(f32x4*)(T + (long long)b * K + col0 + 4 * (threadIdx.x + DR_THREADS * v)) = acc[v];
 }
 
-template <int NV>
+// Round 4: every access goes through a raw buffer instruction with the lane's offset in ONE register and the chunk's offset
+// (16 KiB per chunk of 1024 lanes x 16 bytes) in the scalar operand.  With plain pointers hipcc kept 16 64-bit store addresses
+// alive (20 spilled VGPRs at the 128-register budget of a 1024-thread workgroup, 84 bytes of scratch per lane) and issued the
+// teacher-probability loads of the last pass one at a time, each waited for before its four exponentials; now four are in flight.
+template <int NV, bool GRAD>
 __global__ __launch_bounds__(DR_THREADS) void dino_student_reg_kernel(const float* __restrict__ student, const float* __restrict__ T,
                                                                       float* __restrict__ loss_sum, bf16_t* __restrict__ dstudent, int G,
                                                                       int B, int K, float inv_tau, float gscale) {
   __shared__ float red[DR_THREADS / 64];
   const long long row = blockIdx.x;
   const int b = (int)(row % B);
-  const float* sr = student + row * K;
-  const float* tb = T + (long long)b * K;
+  const unsigned row_bytes = (unsigned)K * 4u;
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(student + row * K), 0, (int)row_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void*)(T + (long long)b * K), 0, (int)row_bytes, 0x00020000);
+  const unsigned lane_off = (unsigned)threadIdx.x * 16u;
   f32x4 x[NV];
   float m = -INFINITY;
 #pragma unroll
+  for (int v = 0; v < NV; ++v)
+    x[v] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, (unsigned)(v * DR_THREADS * 16), 0));
+#pragma unroll
   for (int v = 0; v < NV; ++v) {
-    x[v] = *(const f32x4*)(sr + 4 * (threadIdx.x + DR_THREADS * v)) * inv_tau;
+    x[v] *= inv_tau;
     m = fmaxf(fmaxf(m, fmaxf(x[v][0], x[v][1])), fmaxf(x[v][2], x[v][3]));
   }
   m = block_reduce16(m, red, true);
   float s = 0.f;
 #pragma unroll
-  for (int v = 0; v < NV; ++v) s += (__expf(x[v][0] - m) + __expf(x[v][1] - m)) + (__expf(x[v][2] - m) + __expf(x[v][3] - m));
+  for (int v = 0; v < NV; ++v) {
+    s += (__expf(x[v][0] - m) + __expf(x[v][1] - m)) + (__expf(x[v][2] - m) + __expf(x[v][3] - m));
+    if (NV >= 16 && (v & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // (64 row registers: no room for 64 exponentials in flight)
+  }
   s = block_reduce16(s, red, false);
   const float lse = m + __logf(s);
   const float norm = 1.0f / ((float)G * (float)B * (float)K);
   const float gs = gscale * inv_tau * norm;   // d loss / d logit = gs * (G * p - T)
   float acc = 0.f;
+  __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(GRAD ? dstudent + row * K : (bf16_t*)nullptr), 0,
+                                                                 GRAD ? (int)(row_bytes / 2) : 0, 0x00020000);
+  constexpr int CH = NV >= 4 ? 4 : NV;        // teacher-probability loads in flight
 #pragma unroll
-  for (int v = 0; v < NV; ++v) {
-    const int k = 4 * (threadIdx.x + DR_THREADS * v);
-    const f32x4 ls = x[v] - lse;              // log-softmax
-    const f32x4 t = *(const f32x4*)(tb + k);
-    acc += t[0] * ls[0] + t[1] * ls[1] + t[2] * ls[2] + t[3] * ls[3];
-    if (dstudent) {
-      float d[4];
+  for (int v0 = 0; v0 < NV; v0 += CH) {
+    f32x4 t[CH];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) d[r] = gs * ((float)G * __expf(ls[r]) - t[r]);
-      u32x2 w = {pack_bf2(d[0], d[1]), pack_bf2(d[2], d[3])};
-      *(u32x2*)(dstudent + row * K + k) = w;
+    for (int c = 0; c < CH; ++c)
+      t[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rt, lane_off, (unsigned)((v0 + c) * DR_THREADS * 16), 0));
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const f32x4 ls = x[v0 + c] - lse;       // log-softmax
+      acc += t[c][0] * ls[0] + t[c][1] * ls[1] + t[c][2] * ls[2] + t[c][3] * ls[3];
+      if constexpr (GRAD) {                   // (a template flag: with a run-time test hipcc postponed the dot products above and spilled their operands)
+        float d[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[r] = gs * ((float)G * __expf(ls[r]) - t[c][r]);
+        const u32x2 w = {pack_bf2(d[0], d[1]), pack_bf2(d[2], d[3])};
+        __builtin_amdgcn_raw_buffer_store_b64(w, rd, lane_off >> 1, (unsigned)((v0 + c) * DR_THREADS * 8), 0);
+      }
     }
-    if ((v & 3) == 3) asm volatile("" ::: "memory");
+    if (NV >= 16) __builtin_amdgcn_sched_barrier(0);
   }
   acc = block_reduce16(acc, red, false);
   if (threadIdx.x == 0) atomicAdd(loss_sum, -acc * norm);
@@ -480,8 +500,12 @@ extern "C" int vitssl_dino_loss(const float* teacher, const float* student, cons
       hipLaunchKernelGGL(dino_teacher_reg_kernel<NV>, dim3(B), dim3(DR_THREADS), 0, s, teacher, center, t_ws, G, B, K, 1.0f / teacher_temp); \
       VS_CHECK_LAUNCH("dino_teacher");                                                                                             \
     }                                                                                                                              \
-    hipLaunchKernelGGL(dino_student_reg_kernel<NV>, dim3(V * B), dim3(DR_THREADS), 0, s, student, t_ws, loss_sum,                     \
-                       (bf16_t*)dstudent_bf16, G, B, K, 1.0f / student_temp, gscale);                                              \
+    if (dstudent_bf16)                                                                                                             \
+      hipLaunchKernelGGL((dino_student_reg_kernel<NV, true>), dim3(V * B), dim3(DR_THREADS), 0, s, student, t_ws, loss_sum,           \
+                         (bf16_t*)dstudent_bf16, G, B, K, 1.0f / student_temp, gscale);                                            \
+    else                                                                                                                           \
+      hipLaunchKernelGGL((dino_student_reg_kernel<NV, false>), dim3(V * B), dim3(DR_THREADS), 0, s, student, t_ws, loss_sum,          \
+                         (bf16_t*)nullptr, G, B, K, 1.0f / student_temp, gscale);                                                  \
     VS_CHECK_LAUNCH("dino_student");                                                                                               \
     return VITSSL_OK;                                                                                                              \
   } while (0)
