@@ -24,6 +24,7 @@ KNOBS = [
     ({"VITSSL_TN_PP": "0"}, TN),                      # the two-phase weight-gradient loop
     ({"VITSSL_TN_BATCH_REM": "0", "VITSSL_TN_BATCH_SPLITS": "3"}, TN),   # batched weight gradients: no helper workgroups, forced split count
     ({"VITSSL_ATTN_FWD_PERSIST": "0", "VITSSL_ATTN_BWD_PIPE": "0", "VITSSL_ATTN_STAGGER_BWD": "0"}, ATTN),   # N > 128 on the short-sequence kernels
+    ({"VITSSL_ATTN_BWD_PERSIST": "0"}, ATTN),         # 129-224 tokens: one workgroup per (batch, head) with the pipelined prologue
     ({"VITSSL_TN8_PP": "0"}, FP8_TN),                 # e4m3 weight gradients with all eight waves in step (the round-2 loop)
 ]
 

@@ -1247,6 +1247,406 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(const bf16_t* __rest
 }
 
 
+// ------------------------------------------------------------------ backward, fused, persistent (128 < N <= 224; round 4)
+// attn_bwd_pipe_kernel inside an item loop (one workgroup per CU, items b, b + G, ...), with the next item's operands requested
+// while the current one is swept, so that the 3.2 us prologue of the pipelined kernel (K tile, V fragments, two slices, lse: nothing
+// else runs on the CU meanwhile, 12 times per CU at B = 256, H = 12) shrinks to fragment reads from LDS.  What moves where:
+//   * K': the K tile is dead once its fragments sit in registers (kf, and the K^T fragments of the dQ products: ATTN_BWD_KT_REGS), so
+//     K' lands in it during the sweep; V' lands in a tile of its own (the pipelined kernel reads V with ordinary loads: +28 KiB of LDS,
+//     which is why N > 224 stays on that kernel).  Both are requested right BEHIND the dQ stores of step 1, NS instructions per wave,
+//     and that step's wait leaves them in flight next to the stores (counted vmcnt); step 2's wait covers them.
+//   * slices 0 and 1 of Q', dO', O' are requested at the top of the LAST step: rows 0-63 of the Q / dO tiles were last read in steps
+//     0 / 1, the O ring's slots 0 / 1 before the barrier of step NS - 2; the last step's wait + barrier covers them.
+//   * lse' goes to the other half of a two-row lse buffer (ordinary loads at the top of the last step).
+//   * the dK / dV store windows move from rows 0-127 of the Q tile to rows 64-127 of the Q and dO tiles (slices 2, 3: dead since
+//     steps 2 / 3, NS >= 5), away from the prefetched slices.
+// The item's first barrier (behind the fragment reads) also separates the last dQ products' reads of the exchange image and the
+// store windows of the slower waves from the next item's first writes / requests.
+// (Q8 = the fp8 operand path's extras -- e4m3 image of dqkv, its scale and maximum -- as a template flag: as run-time arguments they
+// cost a dozen scalar registers the bf16 launches never use, in a kernel that is short of them.)
+template <int NS, bool Q8>
+__global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ outp,
+                                                            const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                            bf16_t* __restrict__ dqkv_arg, int N, int H, int nitems,
+                                                            unsigned char* __restrict__ dq8_arg, const float* __restrict__ qscale,
+                                                            float* qamax) {
+  // bf16 launches: dqkv is there, no e4m3 image; fp8 launches: the e4m3 image is there, the bf16 one optional
+  bf16_t* const dqkv = dqkv_arg;
+  unsigned char* const dq8 = Q8 ? dq8_arg : nullptr;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  static_assert(NS >= 5 && NS <= 7, "the persistent backward is built for 129-224 tokens");
+  constexpr int NW = 8;
+  constexpr int Np = 32 * NS;
+  constexpr int TILE = Np * ROWB;
+  constexpr int SROW = Np * 2 + 16;
+  const float qsc = (Q8 && qscale) ? *qscale : 1.0f;
+  float qmax = 0.f;
+  char* Qt = smem;
+  char* Dt = Qt + TILE;
+  char* Kt = Dt + TILE;
+  char* Vt = Kt + TILE;
+  char* Sx = Vt + TILE;                 // 2 x [32][SROW]
+  float* lse_s = (float*)(Sx + 2 * 32 * SROW);      // [2][Np]: this item's / the next item's
+  float* del_s = lse_s + 2 * Np;
+  char* Or = (char*)(del_s + Np);       // ring of three 32-row slices of O
+  const long long stride = 3LL * H * DH, ostride = (long long)H * DH;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const bool has_keys = wave < NS;      // wave-uniform
+  const bool delta_wave = wave == NW - 1;
+  const int dq_stores = ((!Q8 || dqkv) ? 1 : 0) + (Q8 ? 1 : 0);      // vector-memory stores of one dq_tile call (launch-uniform)
+  const int G = gridDim.x;
+  int item = blockIdx.x;
+  if (item >= nitems) return;
+
+  // An item is carried as two element offsets (its q rows in qkv, its rows in out / dout): 4 scalar registers.  The buffer
+  // descriptors are rebuilt where they are used (scalar arithmetic); kept alive for two items they cost 40 scalar registers, the
+  // kernel spilled scalars into vector registers and those into scratch (30-41 VGPRs).
+  struct Item {
+    long long qoff, ooff;
+  };
+  auto item_of = [&](int it) {
+    const int b = it / H, h = it - b * H;
+    Item r;
+    r.qoff = (long long)b * N * stride + h * DH;
+    r.ooff = (long long)b * N * ostride + h * DH;
+    return r;
+  };
+  const int qbytes = (int)((long long)(N - 1) * stride * 2 + ROWB), obytes = (int)((long long)(N - 1) * ostride * 2 + ROWB);
+  // One request = 8 rows x 128 bytes of an operand whose first row is `base`.  The lane's part of the source offset (its row inside
+  // the group, its swizzled chunk: row groups start at multiples of 8 rows, so the chunk XOR depends on the lane only) is ONE
+  // register per row stride; the row group's part goes into the DESCRIPTOR (window = the operand from row grow0 on, scalar
+  // arithmetic, exact range check: rows >= N are zero-filled as before).  Per-call lane offsets, as in dma_rows8, were hoisted out
+  // of the loops by hipcc and cost 40 spilled VGPRs.
+  const int rl8 = lane >> 3;
+  const unsigned lane_q = (unsigned)(rl8 * stride * 2 + (((lane & 7) ^ (((rl8 >> 1) & 3) << 1)) << 4));
+  const unsigned lane_o = (unsigned)(rl8 * ostride * 2 + (((lane & 7) ^ (((rl8 >> 1) & 3) << 1)) << 4));
+  auto dma8 = [&](const bf16_t* base, int total_bytes, long long row_elems, char* lds_rows, unsigned lane_off, int grow0) {
+    const long long skip = (long long)grow0 * row_elems * 2;
+    const int left = total_bytes > skip ? (int)(total_bytes - skip) : 0;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(base + (long long)grow0 * row_elems), 0, left, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds_rows), 16, lane_off, 0, 0, 0);
+  };
+  // slice s = rows 32 s .. 32 s + 31 of Q, dO (into their tiles) and O (into ring slot s % 3): 12 requests of 8 rows,
+  // waves 0-3: one of Q and one of O, waves 4-7: one of dO
+  auto issue_slice = [&](const Item& it, int s) {
+    const int j = wave & 3;
+    const int r0 = 32 * s + 8 * j;
+    if (wave < 4) {
+      dma8(qkv + it.qoff, qbytes, stride, Qt + r0 * ROWB, lane_q, r0);
+      dma8(outp + it.ooff, obytes, ostride, Or + ((s % 3) * 32 + 8 * j) * ROWB, lane_o, r0);
+    } else {
+      dma8(dout + it.ooff, obytes, ostride, Dt + r0 * ROWB, lane_o, r0);
+    }
+  };
+  // the K and V tiles of an item: 2 x 4 NS requests of 8 rows, exactly NS per wave (row group i of K for even, of V for odd turns)
+  auto issue_kv = [&](const Item& it) {
+#pragma unroll
+    for (int n = 0; n < NS; ++n) {
+      const int idx = n * NW + wave;                 // 0 .. 8 NS - 1
+      const int i = idx >> 1;                        // row group of 8 rows, 0 .. 4 NS - 1
+      if (idx & 1) dma8(qkv + it.qoff + 2LL * H * DH, qbytes, stride, Vt + i * 8 * ROWB, lane_q, 8 * i);
+      else dma8(qkv + it.qoff + (long long)H * DH, qbytes, stride, Kt + i * 8 * ROWB, lane_q, 8 * i);
+    }
+  };
+  auto load_lse = [&](int it, int buf) {              // padded queries: p = exp2(x - inf) = 0
+    const int row = threadIdx.x >> 1;                 // 256 >= Np rows, two threads per row
+    const float l = row < N ? lse[(long long)it * N + row] : 0.f;
+    if ((threadIdx.x & 1) == 0 && row < Np) lse_s[buf * Np + row] = row < N ? l * LOG2E : INFINITY;
+  };
+  // delta (pre-multiplied by 1/sqrt(dh)) of slice s, by ONE wave: 2 lanes per row
+  auto delta_slice = [&](int s) {
+    const int rl = lane >> 1, half = lane & 1;
+    const int row = 32 * s + rl;
+    const char* orow = Or + (s % 3) * 32 * ROWB;
+    float part = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u32x4 ov = *(const u32x4*)(orow + tile_off(rl, half * 4 + j));
+      const u32x4 dv = *(const u32x4*)(Dt + tile_off(row, half * 4 + j));
+#pragma unroll
+      for (int w = 0; w < 4; ++w) part += bf_lo(ov[w]) * bf_lo(dv[w]) + bf_hi(ov[w]) * bf_hi(dv[w]);
+    }
+    part += __shfl_xor(part, 1, 64);
+    if (half == 0) del_s[row] = row < N ? part * SCALE : 0.f;
+  };
+
+  // ---- the first item's operands
+  Item cur = item_of(item);
+  issue_kv(cur);
+  issue_slice(cur, 0);
+  issue_slice(cur, 1);
+  load_lse(item, 0);
+  __builtin_amdgcn_s_waitcnt(0x0070);                 // vmcnt(0) lgkmcnt(0)
+  __syncthreads();
+
+  const f32x4 c4 = {SCALE_LOG2E, SCALE_LOG2E, SCALE_LOG2E, SCALE_LOG2E}, sc4 = {SCALE, SCALE, SCALE, SCALE};
+  // transposed-read addresses (as tr_frag): tile base + row 4 g + q, chunk of column slice dt; + 4096 per 32-row step, + 2048
+  // for the second 16 rows, + TILE from the Q tile to the dO tile
+  const int tq = (lane >> 2) & 3, tpp = lane & 3;
+  const unsigned qbase = (unsigned)(size_t)LDS_PTR(Qt);
+  unsigned vrel[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) vrel[dt] = qbase + (unsigned)(tile_off(4 * g + tq, 2 * dt + (tpp >> 1)) + 8 * (tpp & 1));
+  const int dt_w = wave & 3, qt_w = wave >> 2;        // this wave's dQ tile of every step: (query tile, column slice)
+  const unsigned kaddr = vrel[0] - qbase + (unsigned)(size_t)LDS_PTR(Kt) +
+                         (unsigned)(tile_off(4 * g + tq, 2 * dt_w + (tpp >> 1)) - tile_off(4 * g + tq, (tpp >> 1)));
+  f32x4 kinit[2];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) {
+    const float mi = wave * 32 + kt * 16 + li < N ? 0.f : -INFINITY;
+    kinit[kt] = f32x4{mi, mi, mi, mi};
+  }
+
+  for (int par = 0;; par ^= 1) {
+    const int next = item + G;
+    const bool has_next = next < nitems;             // workgroup-uniform
+    const float* lse_c = lse_s + par * Np;
+
+    // ---- item start: K / V fragments and the K^T fragments of the dQ products from the tiles (they landed during the previous item)
+    bf16x8 kf[2][2], vf[2][2];
+    if (has_keys) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          kf[kt][kk] = lds_frag(Kt, wave * 32 + kt * 16 + li, kk, lane);
+          vf[kt][kk] = lds_frag(Vt, wave * 32 + kt * 16 + li, kk, lane);
+        }
+    }
+    s16x4 klo[NS], khi[NS];
+    static_for<NS>([&](auto st_c) {
+      constexpr int st = decltype(st_c)::value;
+      ds_tr16<4096 * st>(klo[st], kaddr);
+      ds_tr16<4096 * st + 2048>(khi[st], kaddr);
+    });
+    if (delta_wave) delta_slice(0);
+    // lgkmcnt(0): the K / V tiles are free behind the barrier.  A raw s_barrier: __syncthreads() would also wait for the previous
+    // item's last stores (vmcnt(0)), which step 0's own wait absorbs half a step later.
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+
+    auto dq_tile = [&](const char* sx, int qs) {
+      const char* rowp = sx + (16 * qt_w + li) * SROW + 8 * g;
+      u32x2 dlo[NS], dhi[NS];
+#pragma unroll
+      for (int st = 0; st < NS; ++st) {
+        dlo[st] = *(const u32x2*)(rowp + 64 * st);        // keys 32st + 4g .. +3
+        dhi[st] = *(const u32x2*)(rowp + 64 * st + 32);   // keys 32st + 16 + 4g .. +3
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+      for (int st = 0; st < NS; ++st) {
+        const u32x4 w = {dlo[st][0], dlo[st][1], dhi[st][0], dhi[st][1]};
+        if (st & 1) acc1 = MFMA16(join_tr(klo[st], khi[st]), __builtin_bit_cast(bf16x8, w), acc1);
+        else acc0 = MFMA16(join_tr(klo[st], khi[st]), __builtin_bit_cast(bf16x8, w), acc0);
+      }
+      const f32x4 acc = acc0 + acc1;
+      const int q = qs * 32 + 16 * qt_w + li;
+      // unconditional stores through descriptors (rows >= N are out of range and dropped): every wave issues exactly one
+      // store per image and call, so the step's wait can be a counted one that leaves them in flight
+      // (descriptors of this item's dq rows, [N, 3 H dh] with row stride `stride`, built here from the item's q offset: scalar work)
+      const unsigned qoff = (unsigned)q * (unsigned)(stride * 2) + (unsigned)((dt_w * 16 + 4 * g) * 2);
+      if (!Q8 || dqkv) {
+        __amdgpu_buffer_rsrc_t rsDQ = __builtin_amdgcn_make_buffer_rsrc((void*)(dqkv + cur.qoff), 0, (int)((long long)(N - 1) * stride * 2 + ROWB), 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3])}, rsDQ, qoff, 0, 0);
+      }
+      if constexpr (Q8) {
+        __amdgpu_buffer_rsrc_t rsDQ8 = __builtin_amdgcn_make_buffer_rsrc((void*)(dq8 + cur.qoff), 0, (int)((long long)(N - 1) * stride + DH), 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b32(pack_fp8x4(acc[0] * qsc, acc[1] * qsc, acc[2] * qsc, acc[3] * qsc), rsDQ8, qoff >> 1, 0, 0);
+        if (q < N) qmax = fmaxf(qmax, fmaxf(fmaxf(fabsf(acc[0]), fabsf(acc[1])), fmaxf(fabsf(acc[2]), fabsf(acc[3]))));
+      }
+    };
+
+    f32x4 dv[4][2], dk[4][2];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        dv[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dk[dt][kt] = dv[dt][kt];
+      }
+
+#pragma unroll 1
+    for (int qs = 0; qs < NS; ++qs) {
+      char* sx = Sx + (qs & 1) * 32 * SROW;
+      // (the next item's offsets are worked out inside the two branches that use them, from an opaque copy of its index: hoisted
+      // in front of the sweep they -- and the descriptors built from them -- stay alive through every step; this kernel is short of
+      // scalar registers, spilled scalars are read back through v_readlane)
+      int nz = next;
+      asm volatile("" : "+s"(nz));
+      if (qs + 2 < NS) issue_slice(cur, qs + 2);
+      if (qs == NS - 1 && has_next) {                  // the next item's first two slices and its lse row
+        const Item nx = item_of(nz);
+        issue_slice(nx, 0);
+        issue_slice(nx, 1);
+        load_lse(nz, par ^ 1);
+      }
+      if (delta_wave && qs + 1 < NS) delta_slice(qs + 1);       // slice qs + 1 landed with the wait that ended step qs - 1
+      f32x4 p[2][2], ds[2][2];  // [query tile in step][key tile]
+      if (has_keys) {
+        f32x4 a[2][2], c[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int qrow = qs * 32 + t * 16 + li;
+          const bf16x8 qa0 = lds_frag(Qt, qrow, 0, lane), qa1 = lds_frag(Qt, qrow, 1, lane);
+          const bf16x8 da0 = lds_frag(Dt, qrow, 0, lane), da1 = lds_frag(Dt, qrow, 1, lane);
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt) {
+            a[t][kt] = kinit[kt];
+            c[t][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            a[t][kt] = MFMA16(qa0, kf[kt][0], a[t][kt]);
+            a[t][kt] = MFMA16(qa1, kf[kt][1], a[t][kt]);
+            c[t][kt] = MFMA16(da0, vf[kt][0], c[t][kt]);
+            c[t][kt] = MFMA16(da1, vf[kt][1], c[t][kt]);
+          }
+        }
+        if (qs > 0) dq_tile(Sx + ((qs - 1) & 1) * 32 * SROW, qs - 1);
+        if (qs == 1 && has_next) issue_kv(item_of(nz));   // behind this step's dQ stores: both may stay in flight at its wait
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const f32x4 nl = -*(const f32x4*)(lse_c + qs * 32 + t * 16 + 4 * g);
+          const f32x4 nd = -*(const f32x4*)(del_s + qs * 32 + t * 16 + 4 * g);
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt) {
+            const f32x4 e = __builtin_elementwise_fma(a[t][kt], c4, nl);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[t][kt][r] = __builtin_amdgcn_exp2f(e[r]);
+            ds[t][kt] = p[t][kt] * __builtin_elementwise_fma(c[t][kt], sc4, nd);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              *(bf16_t*)(sx + (16 * t + 4 * g + r) * SROW + (32 * wave + 16 * kt + li) * 2) = f2bf(ds[t][kt][r]);
+          }
+        }
+      } else {
+        if (qs > 0) dq_tile(Sx + ((qs - 1) & 1) * 32 * SROW, qs - 1);
+        if (qs == 1 && has_next) issue_kv(item_of(nz));
+      }
+      // end of the step's first half: this wave's dS columns, its delta rows and its share of slice qs + 2 are complete.  The dQ
+      // store(s) of this step -- and, in step 1, the NS requests of the next item's K / V tiles -- were issued AFTER the slice's
+      // requests and may stay in flight (counted vmcnt); lgkmcnt(0) covers the LDS writes.  Step 0 waits for everything: the
+      // previous item's last stores are older than slice 2's requests and have had the step's first half to be acknowledged.
+      const int fly = (qs == 0 ? 0 : dq_stores) + ((qs == 1 && has_next) ? NS : 0);
+      switch (fly) {                                    // (immediates: lgkmcnt(0), expcnt untouched, vmcnt = fly)
+        case 0: __builtin_amdgcn_s_waitcnt(0x0070); break;
+        case 1: __builtin_amdgcn_s_waitcnt(0x0071); break;
+        case 2: __builtin_amdgcn_s_waitcnt(0x0072); break;
+        case 5: __builtin_amdgcn_s_waitcnt(0x0075); break;
+        case 6: __builtin_amdgcn_s_waitcnt(0x0076); break;
+        case 7: __builtin_amdgcn_s_waitcnt(0x0077); break;
+        case 8: __builtin_amdgcn_s_waitcnt(0x0078); break;
+        case 9: __builtin_amdgcn_s_waitcnt(0x0079); break;
+        default: __builtin_amdgcn_s_waitcnt(0x0070); break;
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" ::: "memory");
+      if (has_keys) {
+        // dV^T += dO^T P, dK^T += Q^T dS: the transposed fragments of the step's 32 rows serve both key tiles
+        s16x4 qlo[4], qhi[4], dlo[4], dhi[4];
+        const unsigned soff = (unsigned)qs * 4096u;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          ds_tr16<TILE>(dlo[dt], vrel[dt] + soff);
+          ds_tr16<TILE + 2048>(dhi[dt], vrel[dt] + soff);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          ds_tr16<0>(qlo[dt], vrel[dt] + soff);
+          ds_tr16<2048>(qhi[dt], vrel[dt] + soff);
+        }
+        bf16x8 pf[2], sf[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          pf[kt] = pack_frag(p[0][kt], p[1][kt]);
+          sf[kt] = pack_frag(ds[0][kt], ds[1][kt]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");      // the dO fragments are in; the Q fragments land under the dV MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const bf16x8 dfr = join_tr(dlo[dt], dhi[dt]);
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt) dv[dt][kt] = MFMA16(dfr, pf[kt], dv[dt][kt]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const bf16x8 qfr = join_tr(qlo[dt], qhi[dt]);
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt) dk[dt][kt] = MFMA16(qfr, sf[kt], dk[dt][kt]);
+        }
+      }
+    }
+    dq_tile(Sx + ((NS - 1) & 1) * 32 * SROW, NS - 1);
+    if (has_keys) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        const int key = wave * 32 + kt * 16 + li;
+        if (!Q8 || dqkv) {
+          // Line-shaped stores (as the NT GEMM epilogue): the 16 x 128-byte tile goes through a private 2 KiB LDS window and leaves
+          // as 8 rows x 128 contiguous bytes per instruction.  Windows: rows 64-127 (slices 2 and 3, dead since steps 2 / 3) of the
+          // Q tile (waves 0-3) and of the dO tile (waves 4-7); rows 0-63 hold the next item's first slices by now.
+          char* xw = (wave < 4 ? Qt : Dt) + 64 * ROWB + (wave & 3) * 2048;
+          int lz = lane;                                  // (opaque copy: the store addressing below is formed here, not in front of the sweep)
+          asm volatile("" : "+v"(lz));
+          const int rho = lz >> 3, kap = lz & 7, gz = lz >> 4, liz = lz & 15;
+          const unsigned tw = (unsigned)(liz * 128 + ((gz ^ (2 * (liz >> 1))) << 3));
+          const unsigned tr = (unsigned)(rho * 128 + ((kap ^ (rho >> 1)) << 4));
+          const int key_a = wave * 32 + kt * 16 + rho;
+          bf16_t* dka = dqkv + cur.qoff + (long long)key_a * stride + (long long)H * DH + 8 * kap;
+#pragma unroll
+          for (int tsel = 0; tsel < 2; ++tsel) {        // dK, then dV
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) *(u32x2*)(xw + (tw ^ (unsigned)(32 * dt))) = pack4(tsel == 0 ? dk[dt][kt] : dv[dt][kt]);
+            const u32x4 s1 = *(const u32x4*)(xw + tr), s2 = *(const u32x4*)(xw + ((tr + 1024u) ^ 64u));
+            bf16_t* dst = dka + (long long)tsel * H * DH;
+            if (key_a < N) *(u32x4*)dst = s1;
+            if (key_a + 8 < N) *(u32x4*)(dst + 8 * stride) = s2;
+          }
+        }
+        if constexpr (Q8) {
+          unsigned qk[4], qv[4];
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            const f32x4 a = dk[dt][kt], c = dv[dt][kt];
+            qk[dt] = pack_fp8x4(a[0] * qsc, a[1] * qsc, a[2] * qsc, a[3] * qsc);
+            qv[dt] = pack_fp8x4(c[0] * qsc, c[1] * qsc, c[2] * qsc, c[3] * qsc);
+            if (key < N) {
+              qmax = fmaxf(qmax, fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3]))));
+              qmax = fmaxf(qmax, fmaxf(fmaxf(fabsf(c[0]), fabsf(c[1])), fmaxf(fabsf(c[2]), fabsf(c[3]))));
+            }
+          }
+          const u32x4 rk = lane_rows_transpose4(qk), rv = lane_rows_transpose4(qv);
+          if (key < N) {
+            unsigned char* k8 = dq8 + cur.qoff + (long long)key * stride + (long long)H * DH + 16 * g;
+            *(u32x4*)k8 = rk;
+            *(u32x4*)(k8 + (long long)H * DH) = rv;
+          }
+        }
+      }
+    }
+    if (!has_next) break;
+    item = next;
+    cur = item_of(next);
+  }
+  if (Q8 && qamax) {
+    qmax = wave_max(qmax);
+    unsigned* slot = (unsigned*)qamax;
+    if (lane == 0 && __float_as_uint(qmax) > __builtin_nontemporal_load(slot)) atomicMax(slot, __float_as_uint(qmax));
+  }
+}
+
 // CUs the launches of this file size themselves for: the device's count minus the reserve in force (vitssl_set_reserved_cus).  The
 // persistent forward holds 147-160 KiB of LDS and 8 waves x 256 VGPRs per workgroup, i.e. a whole CU for the whole launch, so its grid
 // must leave the reserved CUs to the collective library like the GEMM grids do (round-3 advisor finding: it used the raw count).
@@ -1317,10 +1717,37 @@ bool attn_bwd_pipe() {
   return knob.get("VITSSL_ATTN_BWD_PIPE", 1) != 0;
 }
 
+// 1 (default): sequences of 129-224 tokens run the persistent backward (next item's operands prefetched); 0: one workgroup per
+// (batch, head) with the pipelined prologue (VITSSL_ATTN_BWD_PERSIST; exercised by tests/test_gpu_knobs.py)
+bool attn_bwd_persist() {
+  static VsEnvInt knob;
+  return knob.get("VITSSL_ATTN_BWD_PERSIST", 1) != 0;
+}
+
 template <int NS>
 int launch_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv, int B,
                int N, int H, hipStream_t s, unsigned char* dq8 = nullptr, const float* qscale = nullptr, float* qamax = nullptr) {
   const int cus = attn_cu_count();
+  if constexpr (NS >= 5 && NS <= 7) {
+    if (attn_bwd_pipe() && attn_bwd_persist()) {
+      static VsOnce done_ps{false}, done_ps8{false};
+      constexpr int LDS_PS = 4 * NS * 32 * ROWB + 2 * 32 * (NS * 64 + 16) + 3 * NS * 32 * 4 + 3 * 32 * ROWB;
+      static_assert(LDS_PS <= 160 * 1024, "the persistent backward needs four operand tiles in LDS");
+      const int nitems = B * H;
+      const int grid = nitems < cus ? nitems : cus;
+      if (dq8) {
+        if (int rc = ensure_lds(attn_bwd_pers_kernel<NS, true>, LDS_PS, &done_ps8, "attn_bwd_pers")) return rc;
+        hipLaunchKernelGGL((attn_bwd_pers_kernel<NS, true>), dim3(grid), dim3(512), LDS_PS, s, qkv, out, dout, lse, dqkv, N, H, nitems, dq8,
+                           qscale, qamax);
+      } else {
+        if (int rc = ensure_lds(attn_bwd_pers_kernel<NS, false>, LDS_PS, &done_ps, "attn_bwd_pers")) return rc;
+        hipLaunchKernelGGL((attn_bwd_pers_kernel<NS, false>), dim3(grid), dim3(512), LDS_PS, s, qkv, out, dout, lse, dqkv, N, H, nitems, dq8,
+                           qscale, qamax);
+      }
+      VS_CHECK_LAUNCH("attn_bwd_pers");
+      return VITSSL_OK;
+    }
+  }
   if constexpr (NS >= 5) {
     if (attn_bwd_pipe()) {
       static VsOnce done_p{false};
