@@ -277,7 +277,10 @@ def other_configs(dev, steps=10, warmup=5):
             lambda: side_simmim("vit_l", 128, "fp8", dev, steps, warmup),
             lambda: side_dino(64, dev, steps, warmup)]
     for job in jobs:
-        rows.append(job())
+        try:
+            rows.append(job())
+        except Exception as e:                               # a side configuration must never cost the headline line
+            rows.append({"error": f"{type(e).__name__}: {e}"[:300]})
         gc.collect()
         torch.cuda.empty_cache()
     return rows
