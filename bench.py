@@ -223,7 +223,7 @@ def side_simmim(model_name, batch, dtype, dev, steps, warmup, img=224, patch=16,
     final = float(loss)
     recomputed = float((model.last_pred - model.last_targets).abs().mean())
     if not (final == final and abs(recomputed - final) <= 1e-4 * max(1.0, abs(final))):
-        raise SystemExit(f"bench sanity ({model_name} {dtype}): fused loss {final} vs recomputed {recomputed}")
+        raise RuntimeError(f"bench sanity ({model_name} {dtype}): fused loss {final} vs recomputed {recomputed}")
     fam, _, _ = instrumented(lambda: model.train_step(x, opt, None))
     N = (img // patch) ** 2
     fl = train_flops_per_image(cfg["D"], cfg["L"], cfg["H"], cfg["F"], N, 3 * patch * patch, int(N * ratio)) * batch
@@ -258,7 +258,7 @@ def side_dino(batch, dev, steps, warmup, dropout=0.1):
     dt = (time.perf_counter() - t0) / steps
     final = float(loss)
     if final != final:
-        raise SystemExit("bench sanity (DINO): loss is NaN")
+        raise RuntimeError("bench sanity (DINO): loss is NaN")
     fam, _, _ = instrumented(step)
     return {"workload": f"ViT-B/16 DINO student+teacher, 2x224 + 8x96 crops, K=65536, EMA 0.996, dropout {dropout} AdamW, batch {batch} image sets/GPU",
             "dtype": "bf16", "steps": steps, "warmup": warmup, "ms_per_step": round(dt * 1e3, 3),
