@@ -760,6 +760,7 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
   }
 
   if (CS && p.colsum) {
+    f32x4 red[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -769,9 +770,30 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
         s += __shfl_xor(s, 2, 64);
         s += __shfl_xor(s, 4, 64);
         s += __shfl_xor(s, 8, 64);
-        const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4) + r;
-        if ((lane & 15) == 0 && n < p.N) atomicAdd(p.colsum + n, s);
+        red[j][r] = s;
       }
+    }
+    if (tls) {
+      // One atomic instruction per wave and tile, 64 lanes on 256 contiguous bytes (the float-atomic path's full-rate shape),
+      // instead of sixteen with four active lanes each: the 64 column sums of the wave pass through its LDS window (column
+      // 16 j + 4 g + r of lane group g -> float slot of that column).  Round 4: the sixteen-instruction form cost ~10 us of a
+      // 266 us dGELU launch (the atomics are paced per instruction, ~50 ns per CU).
+      if ((lane & 15) == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(f32x4*)(xs + (16 * j + 4 * g4) * 4) = red[j];
+      }
+      asm volatile("" ::: "memory");                  // (the wave's LDS operations execute in order; this keeps hipcc from reordering them)
+      const float v = *(const volatile float*)(xs + lane * 4);
+      const int n = n0 + wn * 64 + lane;
+      if (n < p.N) atomicAdd(p.colsum + n, v);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4) + r;
+          if ((lane & 15) == 0 && n < p.N) atomicAdd(p.colsum + n, red[j][r]);
+        }
     }
   }
   if constexpr (Q8EPI) {
