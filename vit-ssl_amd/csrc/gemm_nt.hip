@@ -55,11 +55,6 @@
 #ifndef NT_GPRIME_AUX
 #define NT_GPRIME_AUX 2
 #endif
-// 1: every epilogue load / store instruction touches 8 rows x 128 bytes (whole cache lines; lanes
-// r and r^8 of a 16-lane row exchange halves with a DPP rotate) instead of 16 rows x 64 bytes
-#ifndef NT_ROWS128
-#define NT_ROWS128 0
-#endif
 // 1 (default): the GELU epilogue of the ping-pong kernel reads gelu / gelu' from an LDS table; 0: arithmetic only (A/B builds)
 #ifndef NT_GELU_LUT
 #define NT_GELU_LUT 1
@@ -312,35 +307,6 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
   auto off_elem = [&](int i, int n, unsigned elt) -> unsigned {
     return n < p.N ? ((row_l + 16u * i) * un + (unsigned)n) * elt : OOB;
   };
-  // ---- whole-line access shape: the two 64-byte halves (a, b) of a row's 128-byte line live in
-  // the same lane; lanes 0-7 of each 16-lane row keep rows r and take row r's... see line128_*
-  const unsigned row7 = (unsigned)(wm * CFG::WROWS + (lane & 7));        // + 16 i + 8 half
-  const int hsel = (lane >> 3) & 1;                                      // which 64-byte half this lane addresses
-  auto off_bf16_line = [&](int i, int half) -> unsigned {                // bf16 image, pair = hsel
-    const int n = n0 + wn * 64 + (2 * hsel + odd) * 16 + 4 * (g4 - odd);
-    return n < p.N ? ((row7 + 16u * i + 8u * half) * un + (unsigned)n) * 2u : OOB;
-  };
-  auto off_f32_line = [&](int i, int jp, int half) -> unsigned {         // fp32 image, tile h = hsel of pair jp
-    const int n = n0 + wn * 64 + (2 * jp + hsel) * 16 + 4 * g4;
-    return n < p.N ? ((row7 + 16u * i + 8u * half) * un + (unsigned)n) * 4u : OOB;
-  };
-  // (a, b) = the lane's two halves of row r.  to_lines: s1 = rows 0-7 (lanes 0-7 keep a, lanes 8-15
-  // receive b of lane r-8), s2 = rows 8-15 (lanes 0-7 receive a of lane r+8, lanes 8-15 keep b).
-  // from_lines is the inverse.  row_ror:8 = 0x128; bank mask 0xC = lanes 8-15, 0x3 = lanes 0-7.
-  auto to_lines = [&](const u32x4& a, const u32x4& b, u32x4& s1, u32x4& s2) {
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      s1[d] = (unsigned)__builtin_amdgcn_update_dpp((int)a[d], (int)b[d], 0x128, 0xF, 0xC, false);
-      s2[d] = (unsigned)__builtin_amdgcn_update_dpp((int)b[d], (int)a[d], 0x128, 0xF, 0x3, false);
-    }
-  };
-  auto from_lines = [&](const u32x4& l1, const u32x4& l2, u32x4& a, u32x4& b) {
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      a[d] = (unsigned)__builtin_amdgcn_update_dpp((int)l1[d], (int)l2[d], 0x128, 0xF, 0xC, false);
-      b[d] = (unsigned)__builtin_amdgcn_update_dpp((int)l2[d], (int)l1[d], 0x128, 0xF, 0x3, false);
-    }
-  };
   auto pack_pair = [&](const u32x2& w0, const u32x2& w1) -> u32x4 {
     // after the swap: even lane rows hold tile 2jp cols 4g .. 4g+7, odd rows tile 2jp+1 cols 4(g-1) .. 4(g-1)+7
     auto lo = __builtin_amdgcn_permlane16_swap(w0[0], w1[0], false, false);
@@ -388,15 +354,8 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
       __builtin_amdgcn_raw_buffer_store_b128(s2, rs, off_line16(i, 1), 0, AUXV);
     } else if (wide) {
       const u32x4 a = pack_pair(w[0][0], w[0][1]), b = pack_pair(w[1][0], w[1][1]);
-      if (NT_ROWS128) {
-        u32x4 s1, s2;
-        to_lines(a, b, s1, s2);
-        __builtin_amdgcn_raw_buffer_store_b128(s1, rs, off_bf16_line(i, 0), 0, AUXV);
-        __builtin_amdgcn_raw_buffer_store_b128(s2, rs, off_bf16_line(i, 1), 0, AUXV);
-      } else {
-        __builtin_amdgcn_raw_buffer_store_b128(a, rs, off_bf16_wide(i, 0), 0, AUXV);
-        __builtin_amdgcn_raw_buffer_store_b128(b, rs, off_bf16_wide(i, 1), 0, AUXV);
-      }
+      __builtin_amdgcn_raw_buffer_store_b128(a, rs, off_bf16_wide(i, 0), 0, AUXV);
+      __builtin_amdgcn_raw_buffer_store_b128(b, rs, off_bf16_wide(i, 1), 0, AUXV);
     } else {
 #pragma unroll
       for (int jp = 0; jp < 2; ++jp) {
@@ -419,11 +378,6 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
       const u32x4 s1 = *(const u32x4*)(xs + tr32a), s2 = *(const u32x4*)(xs + tr32a + 1024);
       __builtin_amdgcn_raw_buffer_store_b128(s1, rs, off_line32(i, jp, 0), 0, F32_AUX);
       __builtin_amdgcn_raw_buffer_store_b128(s2, rs, off_line32(i, jp, 1), 0, F32_AUX);
-    } else if (NT_ROWS128) {
-      u32x4 s1, s2;
-      to_lines(__builtin_bit_cast(u32x4, v0), __builtin_bit_cast(u32x4, v1), s1, s2);
-      __builtin_amdgcn_raw_buffer_store_b128(s1, rs, off_f32_line(i, jp, 0), 0, F32_AUX);
-      __builtin_amdgcn_raw_buffer_store_b128(s2, rs, off_f32_line(i, jp, 1), 0, F32_AUX);
     } else {
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), rs, off_elem(i, nnp[0], 4u), 0, F32_AUX);
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), rs, off_elem(i, nnp[1], 4u), 0, F32_AUX);
@@ -495,13 +449,6 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
             // whole lines (8 rows x 128 bytes per instruction); turned into the accumulator layout through the LDS window at use
             res[ii][jp][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_line32(ig + ii, jp, 0), 0, 0));
             res[ii][jp][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_line32(ig + ii, jp, 1), 0, 0));
-          } else if (NT_ROWS128) {
-            const u32x4 l1 = __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_f32_line(ig + ii, jp, 0), 0, 0);
-            const u32x4 l2 = __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_f32_line(ig + ii, jp, 1), 0, 0);
-            u32x4 a, b;
-            from_lines(l1, l2, a, b);
-            res[ii][jp][0] = __builtin_bit_cast(f32x4, a);
-            res[ii][jp][1] = __builtin_bit_cast(f32x4, b);
           } else {
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -518,10 +465,6 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
           if (tls) {
             raw[ii][0] = __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_line16(ig + ii, 0), 0, 0);    // rows 0-7 of the row tile, whole lines
             raw[ii][1] = __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_line16(ig + ii, 1), 0, 0);    // rows 8-15
-          } else if (NT_ROWS128) {
-            const u32x4 l1 = __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_bf16_line(ig + ii, 0), 0, 0);
-            const u32x4 l2 = __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_bf16_line(ig + ii, 1), 0, 0);
-            from_lines(l1, l2, raw[ii][0], raw[ii][1]);
           } else {
 #pragma unroll
             for (int jp = 0; jp < 2; ++jp) raw[ii][jp] = __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_bf16_wide(ig + ii, jp), 0, 0);
@@ -1360,7 +1303,7 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_nt_pp_kernel(NtParams p)
     // the wave's LDS window for line-shaped stores: its own two B1 staging slots (2 KiB, contiguous) of the buffer whose B1 / A1
     // units are not in flight -- K-tile (last) read them two barriers ago, and this wave itself re-issues them in p0 of the
     // next K-tile, after its epilogue in program order; no other wave ever writes there
-    nt_epilogue<EPI, CFG, F8, GLUT_IMM, NT_LDS_T != 0 && NT_ROWS128 == 0>(p, acc, m0, n0, wm, wn, lane, smem, smem + (buf ^ 1) * BUF + ldsB[1][0]);
+    nt_epilogue<EPI, CFG, F8, GLUT_IMM, NT_LDS_T != 0>(p, acc, m0, n0, wm, wn, lane, smem, smem + (buf ^ 1) * BUF + ldsB[1][0]);
     stamp(round, 2);
 #ifdef VITSSL_NT_STAMPS
     if (p.stamps) {                                    // diagnostic: when have this wave's stores been acknowledged?
