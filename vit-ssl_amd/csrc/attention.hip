@@ -641,8 +641,10 @@ __global__ __launch_bounds__(1024 / QT, QT == 1 ? 4 : 2) void attn_fwd_pers_kern
 // a wave, each wave then takes two dQ tiles per step) so that two workgroups share a CU --
 // DINO's 96x96 local crops are 37 tokens, and an 8-wave workgroup with six idle waves per
 // (batch, head) was launch-bound (5.8 us per workgroup, as long as a 197-token one).
+// (launch bound: two waves per SIMD.  Without it hipcc spread the 2- and 4-wave forms over 258-284 registers (VGPRs + AGPRs), which
+// admits ONE wave per SIMD: the 37-token launches of DINO's local crops ran two workgroups per CU where the LDS has room for four.)
 template <int NS, int NW>
-__global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ outp,
+__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ outp,
                                                              const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                              bf16_t* __restrict__ dqkv, int N, int H, int stagger_wgs,
                                                              int stagger_ticks, unsigned char* __restrict__ dq8,
