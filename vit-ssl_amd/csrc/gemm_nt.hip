@@ -1265,7 +1265,10 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_nt_pp_kernel(NtParams p)
   section();
 
   constexpr int S = nt_epi_vmem_ops<EPI, MI, F8>();
-  constexpr int NW_POST = (8 + S) > 63 ? 63 : (8 + S);
+#ifndef NT_PROBE_NW
+#define NT_PROBE_NW 8      // timing probe only: any other value reads staging units that may not have landed
+#endif
+  constexpr int NW_POST = (NT_PROBE_NW + S) > 63 ? 63 : (NT_PROBE_NW + S);
   int buf = 0;
 #ifdef VITSSL_NT_STAMPS
   auto stamp = [&](int round, int which) {
@@ -1285,7 +1288,7 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_nt_pp_kernel(NtParams p)
     for (int t = 0; t < nk; ++t) {
       const bool last = t + 1 == nk;
       if (t == 0 && round > 0) ktile(buf, c1, c2, last, IC<NW_POST>{});
-      else ktile(buf, c1, c2, last, IC<8>{});
+      else ktile(buf, c1, c2, last, IC<NT_PROBE_NW>{});
       c1 = c2;
       c2 = cur_next(c2);
       buf ^= 1;
