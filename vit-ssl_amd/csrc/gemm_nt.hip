@@ -66,6 +66,18 @@
 #ifndef NT_RG_DGELU
 #define NT_RG_DGELU 2
 #endif
+// ... with the operand prefetch (two groups alive at once)
+#ifndef NT_RG_RESID_PF
+#define NT_RG_RESID_PF 1
+#endif
+#ifndef NT_RG_DGELU_PF
+#define NT_RG_DGELU_PF 2
+#endif
+// 1: the RESID / DGELU epilogues of the ping-pong kernel request the operand lines of the next row group before they store the
+// current one (see nt_epilogue)
+#ifndef NT_EPI_PREFETCH
+#define NT_EPI_PREFETCH 1
+#endif
 // 1 (default): the ping-pong kernel's epilogue hands every 16-row tile of an output image through a private 2 KiB LDS window
 // of the wave, so that a store instruction's 64 lanes cover 8 rows x 128 CONTIGUOUS bytes with adjacent lanes on adjacent
 // addresses.  tools/probes/store_patterns.hip: a CU stores 55 GB/s in the accumulator layout (adjacent lanes = adjacent ROWS,
@@ -431,12 +443,20 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
   // both residual epilogues among them) take ONE row per group.  Round 3 measured uneven groups (4 + 3) against that,
   // interleaved: N = K = 768 residual 104 -> 109 us, K = 3072 residual 251 -> 247 us, dGELU unchanged -- the phase is
   // bound by bytes, not by round trips (as round 1 found for MI = 8); NT_RG_RESID / NT_RG_DGELU keep the experiment.
-  constexpr int RG = EPI == VITSSL_EPI_RESID ? (MI % 2 == 0 ? 2 : NT_RG_RESID) : (EPI == VITSSL_EPI_DGELU ? (MI % 4 == 0 ? 4 : NT_RG_DGELU) : 4);
-#pragma unroll
-  for (int ig = 0; ig < MI; ig += RG) {
-    const int cnt = MI - ig < RG ? MI - ig : RG;      // (a constant once the loop is unrolled)
-    f32x4 res[RG][2][2];     // RESID: residual stream
-    u32x2 gpre[RG][2][2];    // DGELU: g' in accumulator layout
+  // Operand prefetch (NT_EPI_PREFETCH, line-shaped form only): the residual / g' lines of group g+1 are requested BEFORE group g
+  // is computed and stored.  The vector-memory counter retires in issue order, so in the plain order (loads of g+1 behind the
+  // stores of g) the wait for a group's operands also waited for the previous group's stores to be acknowledged by the L2 --
+  // one load round trip plus one store round trip per group, 7 times per tile for the 224-row residual epilogue.
+  constexpr bool PREF = NT_EPI_PREFETCH != 0 && TLS && (EPI == VITSSL_EPI_RESID || EPI == VITSSL_EPI_DGELU);
+  // (with the prefetch two groups of operands are alive at once: 1 row per group for the residual lines, 2 for g')
+  constexpr int RG = EPI == VITSSL_EPI_RESID ? (PREF ? NT_RG_RESID_PF : (MI % 2 == 0 ? 2 : NT_RG_RESID))
+                     : EPI == VITSSL_EPI_DGELU ? (PREF ? NT_RG_DGELU_PF : (MI % 4 == 0 ? 4 : NT_RG_DGELU))
+                                               : 4;
+  constexpr int NB = PREF ? 2 : 1;
+  f32x4 res[NB][RG][2][2];   // RESID: residual stream (line layout until used)
+  u32x4 raw[NB][RG][2];      // DGELU, 16-byte form: g' as loaded
+  auto load_group = [&](const int ig, const int b) {
+    const int cnt = MI - ig < RG ? MI - ig : RG;
     if constexpr (EPI == VITSSL_EPI_RESID) {
 #pragma unroll
       for (int ii = 0; ii < RG; ++ii)
@@ -444,32 +464,47 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
         for (int jp = 0; jp < 2; ++jp) {
           if (ii >= cnt) continue;
           if (NT_ABLATE == 2) {
-            res[ii][jp][0] = res[ii][jp][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            res[b][ii][jp][0] = res[b][ii][jp][1] = f32x4{0.f, 0.f, 0.f, 0.f};
           } else if (tls) {
             // whole lines (8 rows x 128 bytes per instruction); turned into the accumulator layout through the LDS window at use
-            res[ii][jp][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_line32(ig + ii, jp, 0), 0, 0));
-            res[ii][jp][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_line32(ig + ii, jp, 1), 0, 0));
+            res[b][ii][jp][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_line32(ig + ii, jp, 0), 0, 0));
+            res[b][ii][jp][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_line32(ig + ii, jp, 1), 0, 0));
           } else {
 #pragma unroll
             for (int h = 0; h < 2; ++h)
-              res[ii][jp][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_elem(ig + ii, nn[jp][h], 4u), 0, 0));
+              res[b][ii][jp][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_elem(ig + ii, nn[jp][h], 4u), 0, 0));
           }
         }
     }
     if constexpr (EPI == VITSSL_EPI_DGELU) {
       if (wide) {
-        u32x4 raw[RG][2];
 #pragma unroll
         for (int ii = 0; ii < RG; ++ii) {
           if (ii >= cnt) continue;
           if (tls) {
-            raw[ii][0] = __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_line16(ig + ii, 0), 0, 0);    // rows 0-7 of the row tile, whole lines
-            raw[ii][1] = __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_line16(ig + ii, 1), 0, 0);    // rows 8-15
+            raw[b][ii][0] = __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_line16(ig + ii, 0), 0, 0);    // rows 0-7 of the row tile, whole lines
+            raw[b][ii][1] = __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_line16(ig + ii, 1), 0, 0);    // rows 8-15
           } else {
 #pragma unroll
-            for (int jp = 0; jp < 2; ++jp) raw[ii][jp] = __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_bf16_wide(ig + ii, jp), 0, 0);
+            for (int jp = 0; jp < 2; ++jp) raw[b][ii][jp] = __builtin_amdgcn_raw_buffer_load_b128(rsAux, off_bf16_wide(ig + ii, jp), 0, 0);
           }
         }
+      }
+    }
+  };
+  if constexpr (PREF) load_group(0, 0);
+#pragma unroll
+  for (int ig = 0; ig < MI; ig += RG) {
+    const int cnt = MI - ig < RG ? MI - ig : RG;      // (a constant once the loop is unrolled)
+    const int gb = PREF ? (ig / RG) & 1 : 0;
+    if constexpr (PREF) {
+      if (ig + RG < MI) load_group(ig + RG, gb ^ 1);
+    } else {
+      load_group(ig, 0);
+    }
+    u32x2 gpre[RG][2][2];    // DGELU: g' in accumulator layout
+    if constexpr (EPI == VITSSL_EPI_DGELU) {
+      if (wide) {
 #pragma unroll
         for (int ii = 0; ii < RG; ++ii)
 #pragma unroll
@@ -477,16 +512,16 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
             if (ii >= cnt) continue;
             if (tls) {
               if (jp == 0) {                        // (both pairs at once: the window holds the whole row tile)
-                *(u32x4*)(xs + tr16a) = raw[ii][0];
-                *(u32x4*)(xs + ((tr16a + 1024u) ^ 64u)) = raw[ii][1];
+                *(u32x4*)(xs + tr16a) = raw[gb][ii][0];
+                *(u32x4*)(xs + ((tr16a + 1024u) ^ 64u)) = raw[gb][ii][1];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) gpre[ii][j >> 1][j & 1] = *(const u32x2*)(xs + (tw16 ^ (unsigned)(32 * j)));
               }
               continue;
             }
             // inverse of the store shuffle (the swap is an involution)
-            auto sa = __builtin_amdgcn_permlane16_swap(raw[ii][jp][0], raw[ii][jp][2], false, false);
-            auto sb = __builtin_amdgcn_permlane16_swap(raw[ii][jp][1], raw[ii][jp][3], false, false);
+            auto sa = __builtin_amdgcn_permlane16_swap(raw[gb][ii][jp][0], raw[gb][ii][jp][2], false, false);
+            auto sb = __builtin_amdgcn_permlane16_swap(raw[gb][ii][jp][1], raw[gb][ii][jp][3], false, false);
             gpre[ii][jp][0] = u32x2{sa[0], sb[0]};
             gpre[ii][jp][1] = u32x2{sa[1], sb[1]};
           }
@@ -620,10 +655,10 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
           store_f32_pair(rsOut0, i, jp, v[0], v[1], nn[jp]);
         } else if constexpr (EPI == VITSSL_EPI_RESID) {
           if (tls && NT_ABLATE != 2) {            // the pair's residual lines -> accumulator layout (inverse of store_f32_pair's path)
-            *(f32x4*)(xs + tr32a) = res[ii][jp][0];
-            *(f32x4*)(xs + tr32a + 1024) = res[ii][jp][1];
-            res[ii][jp][0] = *(const f32x4*)(xs + tw32);
-            res[ii][jp][1] = *(const f32x4*)(xs + (tw32 ^ 64u));
+            *(f32x4*)(xs + tr32a) = res[gb][ii][jp][0];
+            *(f32x4*)(xs + tr32a + 1024) = res[gb][ii][jp][1];
+            res[gb][ii][jp][0] = *(const f32x4*)(xs + tw32);
+            res[gb][ii][jp][1] = *(const f32x4*)(xs + (tw32 ^ 64u));
           }
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
@@ -631,9 +666,9 @@ __device__ __forceinline__ void nt_epilogue(const NtParams& p, f32x4 (&acc)[4][C
               bool keep[4];
               drop_keep4(p.dk, drop_words_a0(p.dk, a0row + (unsigned)i * a0rowstep + a0col[jp][h]), keep);
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[h][r] = fmaf(keep[r] ? v[h][r] : 0.f, p.dk.scale, res[ii][jp][h][r]);
+              for (int r = 0; r < 4; ++r) v[h][r] = fmaf(keep[r] ? v[h][r] : 0.f, p.dk.scale, res[gb][ii][jp][h][r]);
             } else {
-              v[h] += res[ii][jp][h];
+              v[h] += res[gb][ii][jp][h];
             }
           }
           store_f32_pair(rsOut0, i, jp, v[0], v[1], nn[jp]);
