@@ -279,7 +279,8 @@ class GradReducer:
         self.pending_elems = 0
         self.handles = []
         self.cuda = gflat.is_cuda
-        self.comm_stream = torch.cuda.Stream(device=gflat.device) if self.cuda else None
+        # high priority: when a CU frees up, the collective's workgroups are dispatched ahead of the queued GEMM workgroups
+        self.comm_stream = torch.cuda.Stream(device=gflat.device, priority=-1) if self.cuda else None
         self.launched: List[Tuple[int, int]] = []
         self.expect = expect if expect is not None else (0, gflat.numel())
         self.check_coverage = True
