@@ -187,6 +187,10 @@ typedef __attribute__((ext_vector_type(8))) short tn_s16x8;
 #ifndef TN_SETPRIO
 #define TN_SETPRIO 0
 #endif
+// 1: the operand DMA of a partial tile skips the columns past the matrix (A/B builds: 0)
+#ifndef TN_MASK_COLS
+#define TN_MASK_COLS 1
+#endif
 
 
 template <int N>
@@ -254,8 +258,12 @@ __device__ __forceinline__ void tn_pp_unit(const TnUnit& p, char* smem) {
       const int row = r0 + (lane >> 5);
       const int ch16 = lane & 31;
       const int sch16 = (((ch16 >> 1) ^ tn_f(row)) << 1) | (ch16 & 1);
-      voffA[h][e] = (unsigned)((row * (long long)p.N1 + c1) * 2 + sch16 * 16);
-      voffB[h][e] = (unsigned)((row * (long long)p.N2 + c2) * 2 + sch16 * 16);
+      // columns past the operand's width get the out-of-range offset (zero fill, no traffic): without it a partial tile
+      // (ViT-S: 384 = 256 + 128) staged the first columns of the NEXT row in their place -- finite junk that the stores
+      // skip, but 16 KiB per K-tile the CU took in for nothing
+      const bool okA = !TN_MASK_COLS || c1 + sch16 * 8 < p.N1, okB = !TN_MASK_COLS || c2 + sch16 * 8 < p.N2;
+      voffA[h][e] = okA ? (unsigned)((row * (long long)p.N1 + c1) * 2 + sch16 * 16) : 0x80000000u;
+      voffB[h][e] = okB ? (unsigned)((row * (long long)p.N2 + c2) * 2 + sch16 * 16) : 0x80000000u;
       ldsA[h][e] = r0 * 512;
       ldsB[h][e] = B_BASE + r0 * 512;
     }
