@@ -388,3 +388,29 @@ def test_edge_batches_against_oracle(B, img, patch, D, H, F):
     O.l1_loss_mean(pe, te).backward()
     for k, p in model.named_parameters():
         assert rel_l2(p.grad, leaves[k].grad) < 5e-2, (k, rel_l2(p.grad, leaves[k].grad))
+
+
+def test_single_token_image_has_nothing_masked():
+    """int(N * mask_ratio) == 0 (one token per image): the reference indexes with an all-false mask and returns EMPTY pred /
+    targets (vit_core/ssl/simmim/model.py:56-62 there); L1Loss(mean) of them is nan and every gradient zero.  Same here, on
+    the autograd path and in the fused step (which still applies the optimizer: weight decay only)."""
+    from vit_core.ssl.simmim import SimMIMViT
+    from vitssl_hip.optim import FusedAdamW
+    torch.manual_seed(5)
+    model = SimMIMViT(num_blocks=2, input_shape=(3, 8, 8), embed_dim=64, patch_size=8, num_heads=1, mlp_dim=64,
+                      dropout=0.1, mask_ratio=0.6).to(DEV).train()
+    x = torch.rand(3, 3, 8, 8, device=DEV)
+    pred, tgt, bm = model(x, return_bool_mask=True)
+    assert tuple(pred.shape) == (0, 192) and tuple(tgt.shape) == (0, 192) and tuple(bm.shape) == (3, 1, 1) and not bool(bm.any())
+    loss = torch.nn.L1Loss()(pred, tgt)
+    assert torch.isnan(loss)
+    loss.backward()
+    for k, p in model.named_parameters():
+        assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    opt = FusedAdamW(model.flat_store(), lr=1e-2, weight_decay=0.5)
+    out = model.train_step(x, opt)
+    assert torch.isnan(out)
+    after = model.state_dict()
+    for k, v in before.items():
+        assert torch.allclose(after[k], v * (1.0 - 1e-2 * 0.5), rtol=0, atol=1e-7), k      # zero gradients: decay only

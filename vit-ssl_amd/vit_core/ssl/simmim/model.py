@@ -117,6 +117,13 @@ class _SimMIMRuntime:
         Mm = idx_d.numel()
 
         targets = torch.empty(Mm, self.Pd, dtype=F32, device=dev)
+        if Mm == 0:
+            # int(N * mask_ratio) == 0 (a single token, or ratio 0): the reference indexes with an all-false mask and returns
+            # empty pred / targets (simmim/model.py:56-62); nothing observable depends on the encoder then
+            if save:
+                self.save_gen += 1
+                self.rec = dict(B=B, M=M, Mm=0)
+            return torch.empty(0, self.Pd, dtype=F32, device=dev), targets, mask_d.view(B, self.N, 1).bool()
         ops.gather_patches_f32(x, idx_d, targets, self.P)
         tag = "" if save else "tmp."
         x0, patches = self.embed(x, mask_d, tag)
@@ -136,6 +143,10 @@ class _SimMIMRuntime:
         store's flat gradient buffer (caller zeroes it)."""
         st, ws, rec = self.store, self.ws, self.rec
         B, M, Mm = rec["B"], rec["M"], rec["Mm"]
+        if Mm == 0:                                      # empty prediction: every gradient is zero (the buffer already is)
+            if reducer is not None:
+                reducer.ready(0, st.gflat.numel())
+            return
         dev = dpred_bf16.device
         gv = st.gview
         ops.colsum_bf16(dpred_bf16, gv("simmim_head.bias"))
@@ -172,7 +183,8 @@ class _SimMIMFn(Function):
         st.gflat.zero_()
         dp = R.as_f32(dpred)
         dpb = torch.empty(dp.shape, dtype=BF16, device=dp.device)
-        ops.cast_bf16(dp, dpb)
+        if dp.numel() > 0:
+            ops.cast_bf16(dp, dpb)
         rt.backward(dpb)
         grads = [st.gview(n, p.shape).clone() if p.requires_grad else None for n, p in zip(st.names, st.params)]
         return (None, None, None, None, *grads)
@@ -267,9 +279,16 @@ class SimMIMViT(nn.Module):
             n = pred.numel()
             loss_sum = rt.ws.get("loss_sum", (1,), F32, x.device)
             loss_sum.zero_()
-            dpb = rt.ws.get("dpred", tuple(pred.shape), BF16, x.device)
-            ops.l1_loss(pred, targets, loss_sum, dpb, gscale=1.0 / n)
-            rt.backward(dpb, reducer)
+            if n == 0:
+                # no masked token: the reference's L1Loss(mean) of an empty prediction is nan, every gradient zero, and the
+                # optimizer still steps (weight decay only)
+                loss_sum.fill_(float("nan"))
+                n = 1
+                rt.backward(pred, reducer)
+            else:
+                dpb = rt.ws.get("dpred", tuple(pred.shape), BF16, x.device)
+                ops.l1_loss(pred, targets, loss_sum, dpb, gscale=1.0 / n)
+                rt.backward(dpb, reducer)
             gscale = 1.0
             if reducer is not None:
                 reducer.finish()
