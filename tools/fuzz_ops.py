@@ -3,7 +3,8 @@
 shapes the parametrised lists do not name -- ragged M / N, every N % 8 / N % 4 residue class the entry points accept,
 token counts 1..256 -- and prints the first failing shape.
 
-    SEED=1 BUDGET_S=150 python tools/fuzz_ops.py            (exit code 1 on the first failure)"""
+    SEED=1 BUDGET_S=150 [KINDS=nt,tn,attn,ln,nt8,tn8,tnb,simmim,vit,dino] [CASES=n] python tools/fuzz_ops.py
+(exit code 1 on the first failure)"""
 import os
 import random
 import sys
@@ -125,14 +126,16 @@ def dino_case(_ops, B, gi, li, patch, D, H, F, K, G, Lv):
     assert min(w[0] for w in worst.values()) < 8e-2, worst
 
 
-def main():
-    rng = random.Random(int(os.environ.get("SEED", "0")))
-    budget = float(os.environ.get("BUDGET_S", "120"))
+def run(seed=0, kinds="nt,nt,tn,attn,ln,nt8,tn8,tnb", budget_s=120.0, max_cases=None):
+    """Returns 0, or 1 after printing the first failing case.  `max_cases` bounds the sweep by count (a deterministic list of
+    cases for a given seed: tests/test_gpu_fuzz.py), `budget_s` by time."""
+    rng = random.Random(int(seed))
+    budget = float(budget_s)
     t0 = time.time()
     n = 0
     cases = []
-    while time.time() - t0 < budget:
-        kind = rng.choice((os.environ.get("KINDS") or "nt,nt,tn,attn,ln,nt8,tn8,tnb").split(","))
+    while time.time() - t0 < budget and (max_cases is None or n < max_cases):
+        kind = rng.choice(kinds.split(","))
         if kind == "nt":
             big = rng.random() < 0.15
             M = rng.randint(1, 40000) if big else rng.randint(1, 3000)
@@ -190,6 +193,12 @@ def main():
             print(f"{n} cases ok ({time.time() - t0:.0f} s); last: {kind}{args}", flush=True)
     print(f"all {n} cases ok: " + " ".join(f"{k}{a}" for k, a in cases[-12:]))
     return 0
+
+
+def main():
+    mc = os.environ.get("CASES")
+    return run(os.environ.get("SEED", "0"), os.environ.get("KINDS") or "nt,nt,tn,attn,ln,nt8,tn8,tnb",
+               float(os.environ.get("BUDGET_S", "120")), int(mc) if mc else None)
 
 
 if __name__ == "__main__":
