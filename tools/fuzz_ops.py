@@ -60,6 +60,55 @@ def simmim_case(_ops, B, img, patch, D, H, F):
     assert min(w[0] for w in worst.values()) < 5e-2, worst
 
 
+def simmim_drop_case(_ops, B, img, patch, D, H, F, blocks, p):
+    """Dropout ON through the fused train_step (the bench's path): the engine's masks are exported and handed to the oracle;
+    prediction, loss and every parameter gradient (tests/test_gpu_models.py::test_simmim_dropout_backward_... on a random
+    configuration; either oracle rounding mode within 5e-2, see simmim_case)."""
+    import torch
+    from _util import rel_l2
+    from oracle import vit_oracle as O
+    from vit_core import _runtime as R
+    from vit_core.ssl.simmim import SimMIMViT
+    from vit_core.ssl.simmim.masking import draw_mask
+    from vitssl_hip.optim import FusedAdamW
+    import test_gpu_models as TM
+    dev = torch.device("cuda:0")
+    N = (img // patch) ** 2
+    torch.manual_seed(B * 100 + img + blocks)
+    model = SimMIMViT(num_blocks=blocks, input_shape=(3, img, img), embed_dim=D, patch_size=patch, num_heads=H, mlp_dim=F,
+                      dropout=p, mask_ratio=0.6)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(dev).train()
+    x = torch.rand(B, 3, img, img)
+    torch.manual_seed(91)
+    mask = draw_mask(B, N, 0.6)
+    opt = FusedAdamW(model.flat_store(), lr=1e-4, weight_decay=0.0)
+    torch.manual_seed(92)
+    loss = model.train_step(x.to(dev), opt, mask_cpu=mask)
+    st = model.flat_store()
+    grads = {k: st.gview(k).view(sd[k].shape) for k in st.names}
+    pred, tgt = model.last_pred, model.last_targets
+    torch.manual_seed(92)
+    seed = R.next_seed()
+    keeps = TM._export_keeps(p, seed, blocks, B * N, D, F, (B, N))
+    ref = {}
+    for emu in ("bf16", None):
+        leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        pe, te = O.simmim_forward(leaves, x, mask, patch, H, emu=emu, keeps=keeps, p_drop=round(p * 65536) / 65536)
+        assert torch.equal(tgt.cpu(), te) and rel_l2(pred, pe) < (1e-2 if emu else 2e-2), (emu, rel_l2(pred, pe))
+        wl = O.l1_loss_mean(pe, te)
+        wl.backward()
+        assert abs(float(loss) - float(wl.detach())) < 1e-2 * float(wl.detach())
+        ref[emu] = {k: v.grad for k, v in leaves.items()}
+    # A parameter on whose gradient the oracle's own two rounding modes disagree by s (same masks) is allowed 3 s: on one
+    # 16-token image with p = 0.25 the query / key weight gradients of the last block are 4.5-5 % apart between the modes and
+    # this path sits 7 % from either (round 4 triage); everywhere else the bar is the tests' 5e-2.
+    for k in ref[None]:
+        spread = rel_l2(ref["bf16"][k], ref[None][k])
+        err = min(rel_l2(grads[k], ref["bf16"][k]), rel_l2(grads[k], ref[None][k]))
+        assert err < max(5e-2, 3 * spread), (k, err, spread)
+
+
 def vit_case(_ops, B, img, patch, D, H, F, classes):
     """Supervised ViT (conv patch embedding + CLS token, MLP head): logits, attention maps, the cross-entropy value, and every
     gradient of a LINEAR functional sum(logits * R) against the oracle.  The linear functional hands both sides the same
@@ -163,6 +212,12 @@ def run(seed=0, kinds="nt,nt,tn,attn,ln,nt8,tn8,tnb", budget_s=120.0, max_cases=
             H = rng.randint(1, 3)
             args = (rng.randint(1, 6), patch * rng.randint(3, 16 if patch == 8 else 8), patch, 64 * H, H, 64 * rng.randint(1, 6))
             fn = simmim_case
+        elif kind == "simdrop":
+            patch = rng.choice([8, 16])
+            H = rng.randint(1, 3)
+            args = (rng.randint(1, 5), patch * rng.randint(3, 12 if patch == 8 else 8), patch, 64 * H, H, 64 * rng.randint(1, 6),
+                    rng.randint(1, 3), rng.choice([0.05, 0.1, 0.25, 0.5]))
+            fn = simmim_drop_case
         elif kind == "vit":
             patch = rng.choice([8, 16])
             H = rng.randint(1, 3)
