@@ -64,8 +64,18 @@ def test_dropout_mask_statistics(ops):
 # ----------------------------------------------------------------------------- LayerNorm
 @pytest.mark.parametrize("cols", [64, 192, 384, 768, 1024, 2048])
 def test_layernorm_fwd_bwd(ops, cols):
-    torch.manual_seed(cols)
-    rows = 301
+    _layernorm_case(ops, 301, cols)
+
+
+@pytest.mark.parametrize("rows", [2, 302, 4096 + 6])
+def test_layernorm_row_pairs(ops, rows):
+    """The backward takes rows of 384 columns two per wave when the row count is even (csrc/layernorm.hip, PAIR); an odd count (the case above)
+    takes the one-row-per-wave kernel (and so does the forward, always)."""
+    _layernorm_case(ops, rows, 384)
+
+
+def _layernorm_case(ops, rows, cols):
+    torch.manual_seed(cols + rows)
     x = torch.randn(rows, cols) * 2 + 0.5
     gamma = torch.rand(cols) + 0.5
     beta = torch.randn(cols) * 0.1

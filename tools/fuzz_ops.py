@@ -109,6 +109,52 @@ def simmim_drop_case(_ops, B, img, patch, D, H, F, blocks, p):
         assert err < max(5e-2, 3 * spread), (k, err, spread)
 
 
+def simmim_fp8_case(_ops, B, img, patch, D, H, F):
+    """e4m3 operands in every Linear GEMM of the blocks (BASELINE configs[4]'s path) on a random 2-block SimMIM model against
+    the oracle's fp8 mode run with the gradient scales the engine used (tests/test_gpu_fp8.py::test_simmim_fp8_matches_oracle...)."""
+    import torch
+    from _util import rel_l2
+    from oracle import vit_oracle as O
+    from vit_core.ssl.simmim import SimMIMViT
+    from vit_core.ssl.simmim.masking import draw_mask
+    from vitssl_hip import engine
+    dev = torch.device("cuda:0")
+    N = (img // patch) ** 2
+    engine.set_linear_operands("fp8")
+    try:
+        torch.manual_seed(B * 100 + img)
+        model = SimMIMViT(num_blocks=2, input_shape=(3, img, img), embed_dim=D, patch_size=patch, num_heads=H, mlp_dim=F,
+                          dropout=0.0, mask_ratio=0.6)
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        model = model.to(dev).train()
+        x = torch.rand(B, 3, img, img)
+        torch.manual_seed(9)
+        pred, tgt = model(x.to(dev))
+        loss = torch.nn.functional.l1_loss(pred, tgt)
+        loss.backward()
+        torch.manual_seed(9)
+        mask = draw_mask(B, N, 0.6)
+        leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        pe, te = O.simmim_forward(leaves, x, mask, patch, H, emu="fp8", fp8_gscales=model.runtime().stack.fp8_grad_scales().cpu().tolist())
+        assert torch.equal(tgt.cpu(), te) and rel_l2(pred, pe) < 1e-2, rel_l2(pred, pe)
+        wl = O.l1_loss_mean(pe, te)
+        wl.backward()
+        assert abs(float(loss) - float(wl)) < 1e-2 * float(wl)
+        # how much e4m3 operands move each gradient at all (fp8 mode against fp32 mode of the oracle): a gradient that the
+        # quantisation itself moves by s is allowed s between this path and the fp8 mode, at most 0.12 (the loosest bar of
+        # tests/test_gpu_fp8.py): one e4m3 rounding that falls the other way is a 6 % change of that element, and the small,
+        # cancelling query / key weight and position-embedding gradients of 9-token models sit at 9-9.5 % where the quantisation
+        # moves them by 12-14 %; 8e-2 otherwise
+        l32 = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        p32, t32 = O.simmim_forward(l32, x, mask, patch, H, emu=None)
+        O.l1_loss_mean(p32, t32).backward()
+        for k, p in model.named_parameters():
+            err, spread = rel_l2(p.grad, leaves[k].grad), rel_l2(leaves[k].grad, l32[k].grad)
+            assert err < min(0.12, max(8e-2, spread)), (k, err, spread)
+    finally:
+        engine.set_linear_operands("bf16")
+
+
 def vit_case(_ops, B, img, patch, D, H, F, classes):
     """Supervised ViT (conv patch embedding + CLS token, MLP head): logits, attention maps, the cross-entropy value, and every
     gradient of a LINEAR functional sum(logits * R) against the oracle.  The linear functional hands both sides the same
@@ -218,6 +264,11 @@ def run(seed=0, kinds="nt,nt,tn,attn,ln,nt8,tn8,tnb", budget_s=120.0, max_cases=
             args = (rng.randint(1, 5), patch * rng.randint(3, 12 if patch == 8 else 8), patch, 64 * H, H, 64 * rng.randint(1, 6),
                     rng.randint(1, 3), rng.choice([0.05, 0.1, 0.25, 0.5]))
             fn = simmim_drop_case
+        elif kind == "sim8":                                 # e4m3 operands: D and F multiples of 128
+            patch = rng.choice([8, 16])
+            H = rng.choice([2, 4])
+            args = (rng.randint(1, 5), patch * rng.randint(3, 12 if patch == 8 else 8), patch, 64 * H, H, 128 * rng.randint(1, 4))
+            fn = simmim_fp8_case
         elif kind == "vit":
             patch = rng.choice([8, 16])
             H = rng.randint(1, 3)

@@ -166,7 +166,7 @@ struct NtParams {
   const float* qscale;  // device scalar the values are multiplied by before they are quantised into out2 (NULL = 1)
   float* qamax;         // device slot that receives max |value| written to out2, before scaling (atomic max; NULL = none)
 #ifdef VITSSL_NT_STAMPS
-  unsigned long long* stamps;   // diagnostic build only (tools/nt_stamps.py): [wg][2 wave groups][16 rounds][4] x 100 MHz ticks
+  unsigned long long* stamps;   // diagnostic build only (tools/nt_stamps.py): [2: 100 MHz ticks, shader clocks][wg][2 wave groups][16 rounds][4]
 #endif
 };
 
@@ -1309,6 +1309,9 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void gemm_nt_pp_kernel(NtParams p)
   auto stamp = [&](int round, int which) {
     if (p.stamps && (wave & 3) == 0 && lane == 0 && round < 16)
       p.stamps[(((size_t)bid * 2 + wm) * 16 + round) * 4 + which] = __builtin_amdgcn_s_memrealtime();
+    // second half of the buffer: the same points in shader clocks (in-kernel clock = d s_memtime / d s_memrealtime x 100 MHz)
+    if (p.stamps && (wave & 3) == 0 && lane == 0 && round < 16)
+      p.stamps[(size_t)256 * 2 * 16 * 4 + (((size_t)bid * 2 + wm) * 16 + round) * 4 + which] = __builtin_amdgcn_s_memtime();
   };
 #else
   auto stamp = [&](int, int) {};

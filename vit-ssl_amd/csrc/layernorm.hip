@@ -34,6 +34,10 @@ constexpr int LN_THREADS = 256;  // 4 waves = 4 rows in flight per block
 #ifndef LN_FWD_PAIR
 #define LN_FWD_PAIR 0
 #endif
+// 1: the backward processes rows of 384 columns two per wave (ln_bwd_kernel's PAIR form); 0: one row per wave (A/B builds)
+#ifndef LN_ROW_PAIRS
+#define LN_ROW_PAIRS 1
+#endif
 
 // Q8: also emit the e4m3 image of the output (fp8 operand path, unit scale)
 template <int V, bool Q8 = false>
@@ -138,7 +142,13 @@ constexpr int ln_bwd_blocks(int V, bool has_ln, bool has_cs) {
 
 // HAS_LN = false turns the kernel into the plain "mask + cast + column-sum" of g_res.
 // Q8: also write the e4m3 image gm8 = e4m3(gm * *qscale) and record max |gm| in *qamax (fp8 dgrad operand).
-template <int V, bool HAS_LN, bool HAS_CS, bool Q8 = false>
+// PAIR (rows of 384 columns, ViT-S): a wave takes two consecutive rows = one contiguous run of 192 float4 = three full
+// 64-lane vectors, the access shape of a 768-column row.  One row per wave leaves half the lanes of the second vector idle
+// (96 float4 = 64 + 32) and half as many bytes per wave in flight: 57.8 us against 52.2 for M = 50176 (5.3 -> 5.9 TB/s; 33.8 ->
+// 28.9 us at M = 25088; interleaved A/B, MI355X).  The caller passes rows = row pairs and cols = 2 x the row length; a slot
+// (lane, v) belongs to the pair's second row where lane + 64 v >= cols / 8, and the row statistics are reduced per row.  (The
+// same form of the FORWARD kernel was 17 % slower than one row per wave, 24.5 against 21.0 us, and is not built.)
+template <int V, bool HAS_LN, bool HAS_CS, bool Q8 = false, bool PAIR = false>
 __global__ __launch_bounds__(LN_THREADS, ln_bwd_blocks(V, HAS_LN, HAS_CS)) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* g_res,
@@ -151,26 +161,37 @@ __global__ __launch_bounds__(LN_THREADS, ln_bwd_blocks(V, HAS_LN, HAS_CS)) void 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int c4n = cols >> 2;
+  const int c4h = PAIR ? c4n >> 1 : c4n;            // float4 per row
+  static_assert(!PAIR || (HAS_LN && LN_PREFETCH && !Q8), "row pairs are built for the prefetching LayerNorm form, bf16 image");
   f32x4 g[V], acc_dg[V], acc_db[V], acc_cs[V];
+  bool hi[V];                                       // PAIR: the slot holds columns of the pair's second row
 #pragma unroll
   for (int v = 0; v < V; ++v) {
     const int c4 = lane + 64 * v;
+    hi[v] = PAIR && c4 >= c4h;
     acc_dg[v] = f32x4{0.f, 0.f, 0.f, 0.f};
     acc_db[v] = acc_dg[v];
     acc_cs[v] = acc_dg[v];
-    if (HAS_LN && c4 < c4n) g[v] = *(const f32x4*)(gamma + 4 * c4);
+    if (HAS_LN && c4 < c4n) g[v] = *(const f32x4*)(gamma + 4 * (c4 - (hi[v] ? c4h : 0)));
   }
-  const float inv = 1.0f / (float)cols;
+  const float inv = 1.0f / (float)(PAIR ? cols >> 1 : cols);
   const float qs = (Q8 && qscale) ? *qscale : 1.0f;
   float qmax = 0.f;
   // raw operands of one row (HAS_LN): x, residual gradient, packed dy, statistics
   f32x4 nx[V], ngr[V];
   u32x2 ndy[V];
-  float nmu = 0.f, nrs = 0.f;
+  float nmu = 0.f, nrs = 0.f, nmuB = 0.f, nrsB = 0.f;
   auto fetch = [&](long long row) {
     if (!(HAS_LN && LN_PREFETCH) || row >= rows) return;
-    nmu = mean[row];
-    nrs = rstd[row];
+    if constexpr (PAIR) {
+      nmu = mean[2 * row];
+      nrs = rstd[2 * row];
+      nmuB = mean[2 * row + 1];
+      nrsB = rstd[2 * row + 1];
+    } else {
+      nmu = mean[row];
+      nrs = rstd[row];
+    }
 #pragma unroll
     for (int v = 0; v < V; ++v) {
       const int c4 = lane + 64 * v;
@@ -186,7 +207,7 @@ __global__ __launch_bounds__(LN_THREADS, ln_bwd_blocks(V, HAS_LN, HAS_CS)) void 
   for (long long row = (long long)blockIdx.x * 4 + wave; row < rows; row += row_step) {
     f32x4 dx[V];
     if constexpr (HAS_LN && LN_PREFETCH) {
-      const float mu = nmu, rs = nrs;
+      const float mu = nmu, rs = nrs, muB = nmuB, rsB = nrsB;
       f32x4 xh[V], gr[V];
       u32x2 dyp[V];
 #pragma unroll
@@ -196,29 +217,38 @@ __global__ __launch_bounds__(LN_THREADS, ln_bwd_blocks(V, HAS_LN, HAS_CS)) void 
         dyp[v] = ndy[v];
       }
       fetch(row + row_step);                      // in flight during everything below
-      float s1 = 0.f, s2 = 0.f;
+      float s1 = 0.f, s2 = 0.f, s1B = 0.f, s2B = 0.f;
 #pragma unroll
       for (int v = 0; v < V; ++v) {
         const int c4 = lane + 64 * v;
         if (c4 < c4n) {
           const f32x4 d = {bf_lo(dyp[v][0]), bf_hi(dyp[v][0]), bf_lo(dyp[v][1]), bf_hi(dyp[v][1])};
-          xh[v] = (xh[v] - mu) * rs;
+          xh[v] = (xh[v] - (hi[v] ? muB : mu)) * (hi[v] ? rsB : rs);
           const f32x4 dyg = d * g[v];
           acc_dg[v] += d * xh[v];
           acc_db[v] += d;
-          s1 += dyg[0] + dyg[1] + dyg[2] + dyg[3];
+          const float t1 = dyg[0] + dyg[1] + dyg[2] + dyg[3];
           const f32x4 t = dyg * xh[v];
-          s2 += t[0] + t[1] + t[2] + t[3];
+          const float t2 = t[0] + t[1] + t[2] + t[3];
+          if (hi[v]) {
+            s1B += t1;
+            s2B += t2;
+          } else {
+            s1 += t1;
+            s2 += t2;
+          }
         }
       }
       const float m1 = wave_sum(s1) * inv;
       const float m2 = wave_sum(s2) * inv;
+      const float m1B = PAIR ? wave_sum(s1B) * inv : 0.f;
+      const float m2B = PAIR ? wave_sum(s2B) * inv : 0.f;
 #pragma unroll
       for (int v = 0; v < V; ++v) {
         const int c4 = lane + 64 * v;
         if (c4 < c4n) {
           const f32x4 d = {bf_lo(dyp[v][0]), bf_hi(dyp[v][0]), bf_lo(dyp[v][1]), bf_hi(dyp[v][1])};
-          dx[v] = (d * g[v] - m1 - xh[v] * m2) * rs;
+          dx[v] = (d * g[v] - (hi[v] ? m1B : m1) - xh[v] * (hi[v] ? m2B : m2)) * (hi[v] ? rsB : rs);
           if (g_res) dx[v] += gr[v];
           *(f32x4*)(g_out + row * cols + 4 * c4) = dx[v];
         }
@@ -312,8 +342,15 @@ __global__ __launch_bounds__(LN_THREADS, ln_bwd_blocks(V, HAS_LN, HAS_CS)) void 
       }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < cols; c += LN_THREADS)
-      atomicAdd(target + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+    if constexpr (PAIR) {                            // a column's two slots: columns c and c + cols / 2 of the pair
+      const int ch = cols >> 1;
+      for (int c = threadIdx.x; c < ch; c += LN_THREADS)
+        atomicAdd(target + c, (red[0][c] + red[1][c] + red[2][c] + red[3][c]) +
+                                  (red[0][c + ch] + red[1][c + ch] + red[2][c + ch] + red[3][c + ch]));
+    } else {
+      for (int c = threadIdx.x; c < cols; c += LN_THREADS)
+        atomicAdd(target + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+    }
     __syncthreads();
   }
 }
@@ -348,6 +385,21 @@ int launch_ln_bwd(const void* dy, const float* x, const float* mean, const float
   const int on = dk.thr != 0;
   VS_CHECK_ARG(!on || (unsigned long long)rows * (unsigned long long)cols < (1ull << 34),
                "layernorm_bwd / grad_mask_cast: the dropout stream's group counter is 32 bits (rows * cols < 2^34)");
+  if constexpr (HAS_LN && !Q8 && LN_PREFETCH && LN_ROW_PAIRS) {
+    if (cols == 384 && (rows & 1) == 0) {            // two rows per wave (PAIR)
+      const int pgrid = ln_grid(rows / 2, false, 768);
+      if (gm_colsum)
+        hipLaunchKernelGGL((ln_bwd_kernel<3, true, true, false, true>), dim3(pgrid), dim3(LN_THREADS), 0, s, (const bf16_t*)dy, x, mean,
+                           rstd, gamma, g_res, g_out, (bf16_t*)gm, dgamma, dbeta, gm_colsum, dk, on, (long long)(rows / 2), 768,
+                           (unsigned char*)nullptr, (const float*)nullptr, (float*)nullptr);
+      else
+        hipLaunchKernelGGL((ln_bwd_kernel<3, true, false, false, true>), dim3(pgrid), dim3(LN_THREADS), 0, s, (const bf16_t*)dy, x, mean,
+                           rstd, gamma, g_res, g_out, (bf16_t*)gm, dgamma, dbeta, gm_colsum, dk, on, (long long)(rows / 2), 768,
+                           (unsigned char*)nullptr, (const float*)nullptr, (float*)nullptr);
+      VS_CHECK_LAUNCH("layernorm_bwd");
+      return VITSSL_OK;
+    }
+  }
   const int grid = ln_grid(rows, false, cols);
 #define VS_LNB(V)                                                                                                        \
   do {                                                                                                                   \
@@ -376,8 +428,8 @@ extern "C" int vitssl_layernorm_fwd(const float* x, const float* gamma, const fl
                                     float* rstd, int64_t rows, int cols, float eps, void* stream) {
   VS_CHECK_ARG(x && gamma && beta && y_bf16 && mean && rstd, "layernorm_fwd: null pointer");
   VS_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 2048, "layernorm_fwd: cols=%d must be a multiple of 4 and <= 2048", cols);
-  const int grid = ln_grid(rows, true);
   hipStream_t s = (hipStream_t)stream;
+  const int grid = ln_grid(rows, true);
 #define VS_LNF(V)                                                                                                   \
   hipLaunchKernelGGL((ln_fwd_kernel<V, false>), dim3(grid), dim3(LN_THREADS), 0, s, x, gamma, beta, (bf16_t*)y_bf16, mean, rstd, \
                      (long long)rows, cols, eps, (unsigned char*)nullptr)
