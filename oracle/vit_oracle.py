@@ -14,6 +14,9 @@ Two modes:
     attention probabilities/context, MLP hidden).  Used by the GPU parity
     tests to separate "kernel bug" from "bf16 rounding" with a tight tolerance.
 
+    Inside ``with flash_delta():`` the attention BACKWARD of this mode is the flash-style
+    form the HIP path uses (delta = rowsum(dO * O) from the bf16 output; see sdpa()).
+
   * ``emu="fp8"`` : as "bf16", but the four Linear layers of every encoder block
     run their FORWARD product on OCP e4m3fn operands (BASELINE configs[4], "fp8
     weight path"): activations quantised at unit scale (saturating at +-448),
@@ -163,8 +166,63 @@ def softmax_lastdim(s: Tensor) -> Tensor:
     return e / e.sum(dim=-1, keepdim=True)
 
 
+# emu="bf16" only: the BACKWARD of sdpa() as every flash-style kernel (and the HIP path, csrc/attention.hip) computes it,
+# dS = P (dP - delta) with delta = rowsum(dO * O) taken from the bf16-STORED output, instead of autograd's softmax backward
+# on the materialised P (delta = rowsum(P * dP): every row of dS sums to zero exactly).  The two agree to ~2^-9 |dO||O|;
+# where dP is nearly constant over the keys (few, near-identical tokens) dS cancels and the query / key weight gradients
+# move by several per cent.  Off by default (the reference's eager path is the autograd form); the parity sweeps switch it
+# on with `flash_delta()` to tell that conditioning apart from a kernel error.
+_FLASH_DELTA = False
+
+
+class flash_delta:
+    """Context manager: sdpa(emu="bf16") takes its backward in the flash-style form inside the block."""
+
+    def __enter__(self):
+        global _FLASH_DELTA
+        self._old, _FLASH_DELTA = _FLASH_DELTA, True
+        return self
+
+    def __exit__(self, *exc):
+        global _FLASH_DELTA
+        _FLASH_DELTA = self._old
+        return False
+
+
+def _bf(x: Tensor) -> Tensor:
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+class _SdpaFlashBwd(torch.autograd.Function):
+    """Forward of sdpa(emu="bf16") (q, k, v arrive bf16-rounded); backward on bf16 operands with fp32 accumulation:
+    dV = bf16(P)^T dO, dP = dO V^T, delta = rowsum(dO * bf16(O)), dS = bf16(P (dP - delta)), dQ = dS K / sqrt(d),
+    dK = dS^T Q / sqrt(d)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v):
+        sc = 1.0 / math.sqrt(q.shape[-1])
+        p = softmax_lastdim((q @ k.transpose(-2, -1)) * sc)
+        o = _bf(p) @ v
+        ctx.save_for_backward(q, k, v, p, _bf(o))
+        ctx.sc = sc
+        ctx.mark_non_differentiable(p)
+        return o, p
+
+    @staticmethod
+    def backward(ctx, do, _dp):
+        q, k, v, p, ob = ctx.saved_tensors
+        dob = _bf(do)
+        dv = _bf(p).transpose(-2, -1) @ dob
+        dp = dob @ v.transpose(-2, -1)
+        delta = (dob * ob).sum(dim=-1, keepdim=True)
+        ds = _bf(p * (dp - delta))
+        return (ds @ k) * ctx.sc, (ds.transpose(-2, -1) @ q) * ctx.sc, dv
+
+
 def sdpa(q: Tensor, k: Tensor, v: Tensor, emu=None) -> Tuple[Tensor, Tensor]:
     """ScaledDotProductAttention (vit_core/attention.py:20-23): no mask, no dropout."""
+    if _FLASH_DELTA and emu == "bf16":
+        return _SdpaFlashBwd.apply(q, k, v)
     s = q @ k.transpose(-2, -1)
     s = s / math.sqrt(q.shape[-1])
     p = softmax_lastdim(s)

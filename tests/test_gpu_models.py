@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import load_golden, split_prefix, t, rel_l2, max_abs
+from _util import load_golden, split_prefix, t, rel_l2, max_abs, l1_backward_with_signs
 from oracle import vit_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -45,12 +45,12 @@ def test_simmim_matches_reference_golden(name):
     leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     pe, te = O.simmim_forward(leaves, x.cpu(), t(g["mask"]), patch, H, emu="bf16")
     assert rel_l2(pred, pe) < 1e-2
-    O.l1_loss_mean(pe, te).backward()
+    l1_backward_with_signs(pe, te, pred, tgt)             # the oracle's backward starts from the signs this path saw (_util.py)
     ref = split_prefix(g, "grad/")
     for k, p in model.named_parameters():
         assert p.grad is not None, k
-        assert rel_l2(p.grad, ref[k]) < 5e-2, (k, rel_l2(p.grad, ref[k]))
-        assert rel_l2(p.grad, leaves[k].grad) < 5e-2, (k, "emu", rel_l2(p.grad, leaves[k].grad))
+        assert rel_l2(p.grad, ref[k]) < 5e-2, (k, rel_l2(p.grad, ref[k]))      # the reference's own gradients (its own signs)
+        assert rel_l2(p.grad, leaves[k].grad) < 2e-2, (k, "emu", rel_l2(p.grad, leaves[k].grad))
     feat = model.inference_forward(x)
     assert not model.training
     assert rel_l2(feat, t(g["feat"])) < 2e-2
@@ -170,10 +170,10 @@ def test_simmim_dropout_backward_matches_oracle_with_exported_masks(path):
     pe, te = O.simmim_forward(leaves, x, mask, patch, H, emu="bf16", keeps=keeps, p_drop=round(p * 65536) / 65536)
     assert torch.equal(tgt.cpu(), te) and rel_l2(pred, pe) < 1e-2
     wl = O.l1_loss_mean(pe, te)
-    wl.backward()
+    l1_backward_with_signs(pe, te, pred, tgt)             # same d(loss)/d(pred) on both sides (_util.py)
     assert abs(float(loss) - float(wl.detach())) < 1e-2 * float(wl.detach())
     for k in leaves:
-        assert rel_l2(grads[k], leaves[k].grad) < 5e-2, (path, k, rel_l2(grads[k], leaves[k].grad))
+        assert rel_l2(grads[k], leaves[k].grad) < 2e-2, (path, k, rel_l2(grads[k], leaves[k].grad))
 
 
 def test_encoder_block_dropout_backward_matches_oracle_with_exported_masks():
@@ -385,9 +385,9 @@ def test_edge_batches_against_oracle(B, img, patch, D, H, F):
     assert pred.shape == pe.shape and torch.equal(tgt.cpu(), te)
     assert rel_l2(pred, pe) < 1e-2
     torch.nn.L1Loss()(pred, tgt).backward()
-    O.l1_loss_mean(pe, te).backward()
+    l1_backward_with_signs(pe, te, pred, tgt)             # same d(loss)/d(pred) on both sides (_util.py)
     for k, p in model.named_parameters():
-        assert rel_l2(p.grad, leaves[k].grad) < 5e-2, (k, rel_l2(p.grad, leaves[k].grad))
+        assert rel_l2(p.grad, leaves[k].grad) < 2e-2, (k, rel_l2(p.grad, leaves[k].grad))
 
 
 def test_single_token_image_has_nothing_masked():

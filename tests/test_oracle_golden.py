@@ -41,6 +41,34 @@ def test_sdpa_and_block():
         assert rel_l2(leaves[k].grad, gr) < 1e-4, k
 
 
+def test_flash_delta_mode_is_the_bf16_mode_with_another_backward():
+    """`with O.flash_delta():` changes only the BACKWARD of sdpa(emu="bf16") (delta = rowsum(dO * O) from the bf16 output, bf16
+    operands -- the form of csrc/attention.hip): same outputs bit for bit, gradients of the reference's golden q / k / v within
+    bf16 rounding of the autograd form, and the switch is scoped to the block."""
+    g = load_golden("ops")
+    bf = lambda a: t(a).to(torch.bfloat16).float()   # noqa: E731
+    w = torch.randn(t(g["o"]).shape, generator=torch.Generator().manual_seed(3))
+    grads = {}
+    for mode in ("autograd", "flash"):
+        q, k, v = (bf(g[n]).requires_grad_(True) for n in ("q", "k", "v"))
+        if mode == "flash":
+            with O.flash_delta():
+                o, p = O.sdpa(q, k, v, "bf16")
+            assert type(o.grad_fn).__name__ == "_SdpaFlashBwdBackward"
+        else:
+            o, p = O.sdpa(q, k, v, "bf16")
+            assert type(o.grad_fn).__name__ != "_SdpaFlashBwdBackward"      # the switch does not leak out of the block
+        (o * w).sum().backward()
+        grads[mode] = (o.detach(), p.detach(), q.grad, k.grad, v.grad)
+    assert torch.equal(grads["flash"][0], grads["autograd"][0]) and torch.equal(grads["flash"][1], grads["autograd"][1])
+    for a, b in zip(grads["flash"][2:], grads["autograd"][2:]):
+        assert rel_l2(a, b) < 1e-2
+    # fp32 mode never takes it
+    with O.flash_delta():
+        o, _ = O.sdpa(t(g["q"]), t(g["k"]), t(g["v"]))
+    assert rel_l2(o, t(g["o"])) < TOL
+
+
 @pytest.mark.parametrize("name", ["simmim_tiny", "simmim_n196"])
 def test_simmim(name):
     g = load_golden(name)

@@ -34,7 +34,7 @@ class HeadRuntime:
         self.inv_vnorm = self.ws.get("inv_vnorm", (K,), F32, dev)
         ops.weightnorm_fold(st.view(self.g_name), st.view(self.v_name, (K, D)), wf, self.inv_vnorm)
         self.wn = self.ws.get("wn", (K, D), BF16, dev)
-        self.wnt = self.ws.get("wnt", (D, K), BF16, dev)
+        self.wnt = None if st.forward_only else self.ws.get("wnt", (D, K), BF16, dev)   # (operand of the backward only)
         ops.cast_transpose_bf16(wf, self.wn, self.wnt)
         self._fold_key = key
 

@@ -51,7 +51,7 @@ class _DINORuntime:
         self.D, self.K = D, K
         self.stores, self.bb, self.head = {}, {}, {}
         for who in ("teacher", "student"):
-            st = R.FlatStore(model, device, only=lambda n, who=who: n.startswith(who + "_"))
+            st = R.FlatStore(model, device, only=lambda n, who=who: n.startswith(who + "_"), forward_only=(who == "teacher"))
             pre = f"{who}_backbone."
             names = dict(weight=pre + "patch_embedding.proj.weight", bias=pre + "patch_embedding.proj.bias",
                          cls=pre + "patch_embedding.cls_token", pos=pre + "patch_embedding.positional_embedding")

@@ -79,9 +79,13 @@ class FlatStore:
     storage is re-pointed into `self.flat` (and `.grad` into `self.gflat` on request).
     """
 
-    def __init__(self, module: nn.Module, device: torch.device, only: Optional[Callable[[str], bool]] = None):
+    def __init__(self, module: nn.Module, device: torch.device, only: Optional[Callable[[str], bool]] = None,
+                 forward_only: bool = False):
         self.module = module
         self.device = device
+        # forward_only: no backward ever runs through these weights (DINO's teacher): the transposed bf16 images, operands of
+        # the input-gradient GEMMs only, are not kept (a third of the cast's bytes per optimizer step)
+        self.forward_only = bool(forward_only)
         self.names: List[str] = []
         self.params: List[nn.Parameter] = []
         self.offsets: Dict[str, Tuple[int, int]] = {}
@@ -170,7 +174,7 @@ class FlatStore:
     def register_weight(self, key: str, src: Callable[[], torch.Tensor], transposed_too: bool = True, plain: bool = True):
         """Declare a 2-D GEMM weight [N,K]; caches `key` (bf16 [N,K], unless plain=False) and, if asked,
         `key + '.T'` (bf16 [K,N], the operand of the dgrad GEMM)."""
-        self._cast_jobs.append((key, src, transposed_too, plain))
+        self._cast_jobs.append((key, src, transposed_too and not self.forward_only, plain))
 
     def register_fp8_weight(self, key: str, src: Callable[[], torch.Tensor]):
         """Declare a 2-D GEMM weight [N,K] whose GEMM operands are e4m3 images with a per-tensor power-of-two
