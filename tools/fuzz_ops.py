@@ -159,7 +159,7 @@ def simmim_fp8_case(_ops, B, img, patch, D, H, F):
         pe, te = O.simmim_forward(leaves, x, mask, patch, H, emu="fp8", fp8_gscales=model.runtime().stack.fp8_grad_scales().cpu().tolist())
         assert torch.equal(tgt.cpu(), te) and rel_l2(pred, pe) < 2e-2, rel_l2(pred, pe)      # (tests/test_gpu_fp8.py holds 1e-2 on its fixed models; 1.07e-2 seen here on a random one)
         wl = O.l1_loss_mean(pe, te)
-        l1_backward_with_signs(pe, te, pred, tgt, frac=1e-2, mag=1e-1)      # (e4m3 operands: predictions up to 2 % apart)
+        l1_backward_with_signs(pe, te, pred, tgt, frac=3e-2, mag=1e-1)      # (e4m3 operands: predictions up to 2 % apart)
         assert abs(float(loss) - float(wl.detach())) < 1e-2 * float(wl.detach())
         # The bar is set by how much e4m3 operands move each gradient at all (fp8 mode against fp32 mode of the oracle, `spread`):
         # two implementations of the same quantised arithmetic differ where a rounding falls the other way (6 % of that element
