@@ -3,14 +3,13 @@
 #   gpurun_out/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of `bench.py` (11 steps)
 #   gpurun_out/<tag>_pmc_traffic.json   FETCH_SIZE / WRITE_SIZE per kernel family, collected in two
 #                                       SEPARATE --pmc passes of the same command (MI355X_MICROARCH.md)
-#   gpurun_out/<tag>_bench.json         the plain bench line (with cpu_baseline)
+#   gpurun_out/<tag>_bench.json         the plain bench line (with cpu_baseline), taken last so that it carries the PMC traffic
 # usage: bash tools/profile_round.sh r01_final
 set -e
 tag=${1:-rNN}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/prof_$tag
 rm -rf $out
-python3 bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-other-configs > /dev/null 2>&1
 find $out/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${tag}_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -40,4 +39,9 @@ res["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate pass
 json.dump(res, open(dst, "w"), indent=1)
 print(json.dumps({c: {k: round(v["sum_kb"] / max(v["dispatches"], 1)) for k, v in res[c].items()} for c in ("FETCH_SIZE", "WRITE_SIZE")}))
 PY
+# the plain bench line LAST, on the same box: bench.py quotes roofline.traffic only from a profiles/*_pmc_traffic.json stamped with
+# these kernel sources, so the summary just made goes where it looks (the copy under profiles/ of the GPU box is scratch: commit
+# the one merged back into gpurun_out/)
+cp gpurun_out/${tag}_pmc_traffic.json profiles/${tag}_pmc_traffic.json
+python3 bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 tail -c 600 gpurun_out/${tag}_bench.json

@@ -20,7 +20,7 @@
 #include "common.h"
 
 #ifdef VITSSL_TN_STAMPS
-__device__ unsigned long long* g_tn_stamps = nullptr;     // [workgroup][wave group][8]
+__device__ unsigned long long* g_tn_stamps = nullptr;     // [workgroup][wave group][8]: six 10 ns segment sums, K-tiles, shader clocks of the loop
 extern "C" int vitssl_debug_set_tn_stamps(unsigned long long* p) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_tn_stamps), &p, sizeof(p)) == hipSuccess ? 0 : 1;
 }
@@ -410,6 +410,7 @@ __device__ __forceinline__ void tn_pp_unit(const TnUnit& p, char* smem) {
     if (w1 == 1) tn_section();                         // waves 4-7 run one barrier behind waves 0-3
 #ifdef VITSSL_TN_STAMPS
     tprev = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long tclk0 = __builtin_amdgcn_s_memtime();     // shader clocks over the same loop: slot 7
 #endif
     for (int t = 0; t < nk; t += 2) {
       phase(I0{}, I0{}, t, false);
@@ -422,6 +423,7 @@ __device__ __forceinline__ void tn_pp_unit(const TnUnit& p, char* smem) {
     if (g_tn_stamps && p.stamp_wg >= 0 && lane == 0 && (wave & 3) == 0) {
       for (int i = 0; i < 6; ++i) g_tn_stamps[((size_t)p.stamp_wg * 2 + w1) * 8 + i] = tseg[i];
       g_tn_stamps[((size_t)p.stamp_wg * 2 + w1) * 8 + 6] = (unsigned long long)nk;
+      g_tn_stamps[((size_t)p.stamp_wg * 2 + w1) * 8 + 7] = __builtin_amdgcn_s_memtime() - tclk0;
     }
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing zero-fill DMA retired before the LDS is released
