@@ -39,14 +39,23 @@ def run(device):
               for which, cols in ((0, D), (1, F), (2, D))] for i in range(Lb)]
     leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     pred, tgt = O.simmim_forward(leaves, x, mask, P, H, keeps=keeps, p_drop=round(p * 65536) / 65536)
-    ref = O.l1_loss_mean(pred, tgt)
-    ref.backward()
+    ref = O.l1_loss_mean(pred, tgt).detach()
     assert abs(loss - float(ref)) < 1e-2 * float(ref), (loss, float(ref))
+    # The oracle's backward starts from the signs the engine saw: dL1/dpred = sign(pred - target) / n is discontinuous, and one
+    # element of a few thousand whose difference changes sign between the two roundings moves every gradient by per cents
+    # (tests/_util.py::l1_backward_with_signs).  Signs may differ on a handful of elements only, all within rounding of the target.
+    d_e = model.last_pred.detach().float().cpu() - model.last_targets.detach().float().cpu()
+    d_o = pred.detach() - tgt
+    flip = torch.sign(d_e) != torch.sign(d_o)
+    assert int(flip.sum()) <= max(3, int(1e-2 * flip.numel())), (int(flip.sum()), flip.numel())
+    if flip.any():
+        assert float(d_o[flip].abs().max()) < 5e-2 * float(pred.detach().pow(2).mean().sqrt())
+    ((pred * torch.sign(d_e)).sum() / pred.numel()).backward()
     st = model.flat_store()
     worst = 0.0
     for k in st.names:
         a, b = st.gview(k).cpu().double(), leaves[k].grad.reshape(-1).double()
         worst = max(worst, float((a - b).norm() / (b.norm() + 1e-30)))
-    assert worst < 6e-2, worst
+    assert worst < 2e-2, worst        # fp32 oracle, same d(loss)/d(pred); bf16 operand rounding through two blocks (6.2e-3 measured)
     assert torch.equal(model.last_targets.cpu(), tgt)
     print(f"smoke: loss {loss:.6f} (oracle {float(ref):.6f}), worst grad rel-L2 {worst:.3e}")
