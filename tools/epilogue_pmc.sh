@@ -45,11 +45,17 @@ for d in sorted(glob.glob(out + "/e*")):
                                       hbm_bytes_pmc=round(hbm), traffic_ratio=round(hbm / alg, 3), counters=row,
                                       mfma_busy_frac=None if not us else round(row.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024 / (us * 2400.0), 3),
                                       wait_any_frac=None if "SQ_WAVE_CYCLES" not in row else round(row.get("SQ_WAIT_ANY", 0) / max(row["SQ_WAVE_CYCLES"], 1), 3))
+    r = res[f"epi{epi}_N{N}_K{K}"]
+    if us and row.get("SQ_BUSY_CYCLES"):     # the clock the chip held over the launch, and the matrix pipes' share of THOSE cycles
+        r["clock_ghz"] = round(row["SQ_BUSY_CYCLES"] / 32 / us / 1e3, 3)
+        r["mfma_busy_frac_at_clock"] = round(row.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024 / (us * 1e3 * r["clock_ghz"]), 3)
 res["note"] = ("rocprofv3 passes of tools/one_gemm.py (6 launches, first two dropped); FETCH_SIZE doubled (gfx950 wide reads, "
                "MI355X_MICROARCH.md), unit KB; SQ_* summed over the chip; us = median kernel duration of the --kernel-trace pass; "
-               "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES (16 per 16x16x32 MFMA, summed over SIMDs) / 1024 SIMDs / (us x 2.4 GHz peak clock)")
+               "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES (16 per 16x16x32 MFMA, summed over SIMDs) / 1024 SIMDs / (us x 2.4 GHz peak clock); "
+               "clock_ghz = SQ_BUSY_CYCLES (one instance per shader engine, 32 on the chip) / 32 / us: within 3 % of the in-kernel "
+               "s_memtime / s_memrealtime clock of tools/nt_stamps.py; mfma_busy_frac_at_clock uses that clock instead of 2.4 GHz")
 json.dump(res, open(dst, "w"), indent=1)
 for k, v in res.items():
     if k != "note":
-        print(k, v["us"], v["tflops"], v["traffic_ratio"], v["mfma_busy_frac"], v["wait_any_frac"])
+        print(k, v["us"], v["tflops"], v["traffic_ratio"], v["mfma_busy_frac"], v["wait_any_frac"], v.get("clock_ghz"), v.get("mfma_busy_frac_at_clock"))
 PY
