@@ -103,6 +103,27 @@ def pmc_traffic_per_launch(family="gemm_nt", profiles_dir=None):
     return None, None
 
 
+def pmc_clock_ghz(family="gemm_nt", profiles_dir=None):
+    """The clock the chip held over the launches of a kernel family, from the same committed PMC summary (a third --pmc pass,
+    SQ_BUSY_CYCLES: one instance per shader engine, 32 on the chip; clock = sum of busy cycles / 32 / sum of the launches'
+    durations in that pass).  MFMA-dense loops on random data do not run at the 2.4 GHz the peak is quoted at
+    (MI355X_MICROARCH.md, DVFS give-back).  Same stamping rule as pmc_traffic_per_launch; None when the
+    summary has no such pass."""
+    import glob
+    sha = kernel_sources_sha16()
+    for f in reversed(sorted(glob.glob(os.path.join(profiles_dir or os.path.join(ROOT, "profiles"), "*_pmc_traffic.json")))):
+        try:
+            d = json.load(open(f))
+            if d.get("kernel_sources_sha16") != sha:
+                continue
+            c = d["SQ_BUSY_CYCLES"][family]
+            if c["duration_ns"] > 0:
+                return c["sum"] / 32.0 / c["duration_ns"]
+        except (OSError, ValueError, KeyError, TypeError):
+            continue
+    return None
+
+
 def _cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -437,11 +458,16 @@ def main():
         ach = fl / (ms * 1e-3) / 1e12
         traffic, traffic_src = (pmc_traffic_per_launch(name) if args.model == "vit_b" and args.batch == 256 and args.dtype == "bf16"
                                 else (None, None))
+        clock = pmc_clock_ghz(name) if traffic is not None else None
         roofline = {"kernel": KERNEL_NAMES.get(name, name + "_kernel"),
                     "bound": "mfma", "achieved": round(ach, 1), "peak": peak_of(name),
                     "unit": "TFLOP/s", "frac": round(ach / peak_of(name), 4),
                     "traffic": None if traffic is None else round(traffic), "traffic_unit": "bytes/launch (HBM, PMC)",
                     "traffic_source": traffic_src,
+                    # the clock held over this family's launches (PMC, same summary) and the fraction of the peak AT that clock:
+                    # context for `frac`, which stays against the 2.4 GHz peak
+                    "clock_ghz": None if clock is None else round(clock, 3),
+                    "frac_at_clock": None if clock is None else round(ach / (peak_of(name) * clock / 2.4), 4),
                     "launches_per_step": cnt, "avg_launch_ms": round(ms / cnt, 4),
                     "alg_flops_per_launch": fl / cnt,
                     "families": {k: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1), "ms_per_step": round(v[1], 3), "launches": v[2],

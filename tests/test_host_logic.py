@@ -422,3 +422,12 @@ def test_bench_quotes_pmc_traffic_only_for_these_kernel_sources(tmp_path):
     val, src = bench.pmc_traffic_per_launch("gemm_nt", str(tmp_path))
     assert src == "r05_final_pmc_traffic.json" and val == (2 * 100.0 + 100.0) * 1024.0
     assert bench.pmc_traffic_per_launch("gemm_nt", str(tmp_path / "nothing")) == (None, None)
+    # the clock held over the family's launches: same stamping rule; absent pass -> None
+    assert bench.pmc_clock_ghz("gemm_nt", str(tmp_path)) is None
+    busy = {"gemm_nt": {"sum": 32 * 1.9 * 5000.0, "duration_ns": 5000.0, "dispatches": 3}}
+    (tmp_path / "r09_final_pmc_traffic.json").write_text(json.dumps({"SQ_BUSY_CYCLES": {"gemm_nt": {"sum": 1.0, "duration_ns": 1.0}},
+                                                                     "kernel_sources_sha16": "0" * 16}))
+    (tmp_path / "r05_final_pmc_traffic.json").write_text(json.dumps({"FETCH_SIZE": fam, "WRITE_SIZE": fam, "SQ_BUSY_CYCLES": busy,
+                                                                     "kernel_sources_sha16": sha}))
+    assert abs(bench.pmc_clock_ghz("gemm_nt", str(tmp_path)) - 1.9) < 1e-9
+    assert bench.pmc_clock_ghz("attn", str(tmp_path)) is None
